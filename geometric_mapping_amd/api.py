@@ -1,0 +1,239 @@
+"""Host-side mirror of the reference's processing interface, over the C ABI.
+
+The reference's path is four C++ free functions
+(/root/reference include/geometric_mapping/tunnel_processing.hpp:38-54,77-82)
+driven by cloud_cb (/root/reference src/geometric_mapping.cpp:48-125).  This
+module keeps their names, argument order and meaning so the parity tests read
+like the reference's call sites; every method is a thin ctypes call into
+libgm_hip.so (include/gm_hip.h) -- no arithmetic happens in Python.
+
+Clouds are numpy float32 arrays [n,3]; normals are [n,4] = (nx,ny,nz,curvature).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (GM_CFG_DEFAULT, GM_CFG_KEEP_COUNTS, GM_CFG_STAGE_TIMING, GM_CFG_VOXEL_GRID, GM_CLOUD_BIGENDIAN,
+                   GM_CLOUD_DEVICE, GM_ERR_CAPACITY, GM_OK, Cloud, Config, FrameResult, GmError, STAGE_NAMES)
+
+__all__ = ["GeometricMapping", "GmError", "solve_local_frame"]
+
+
+def _f32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class GeometricMapping:
+    """One gm_ctx.  Parameter names and defaults are the node's
+    (/root/reference launch/mapping.launch:7-10, paramHandler.hpp:26-29)."""
+
+    def __init__(self, boxFilterBound=5.0, voxelGridLeafSize=0.5, neighborRadius=0.5, weightingFactor=0.2,
+                 device=0, flags=GM_CFG_DEFAULT, n_slots=1, max_points=0,
+                 ransac_hypotheses=1024, ransac_threshold=0.03, ransac_seed=1):
+        self._L = _lib.load()
+        cfg = Config()
+        self._L.gm_default_config(C.byref(cfg))
+        cfg.flags = flags
+        cfg.boxFilterBound = boxFilterBound
+        cfg.voxelGridLeafSize = voxelGridLeafSize
+        cfg.neighborRadius = neighborRadius
+        cfg.weightingFactor = weightingFactor
+        cfg.device = device
+        cfg.n_slots = n_slots
+        cfg.max_points = max_points
+        cfg.ransac_hypotheses = ransac_hypotheses
+        cfg.ransac_threshold = ransac_threshold
+        cfg.ransac_seed = ransac_seed
+        self.cfg = cfg
+        self._ctx = C.c_void_p()
+        st = self._L.gm_create(C.byref(cfg), C.byref(self._ctx))
+        if st != GM_OK:
+            msg = self._L.gm_last_error(None).decode()
+            self._ctx = None
+            raise GmError(st, msg)
+        self._keep = {}  # slot -> arrays that must outlive an async submit
+
+    # ---- lifetime ----
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.gm_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, st):
+        if st != GM_OK:
+            raise GmError(st, self._L.gm_last_error(self._ctx).decode())
+
+    # ---- cloud descriptors ----
+    @staticmethod
+    def _cloud_from_xyz(xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        if xyz.ndim != 2 or xyz.shape[1] not in (3, 4):
+            raise ValueError("cloud must be [n,3] or [n,4] float32")
+        step = 4 * xyz.shape[1]
+        c = Cloud(xyz.ctypes.data, xyz.shape[0], step, 0, 4, 8, 0)
+        return c, xyz
+
+    @staticmethod
+    def cloud_from_rows(data, n_points, point_step, offsets=(0, 4, 8), bigendian=False):
+        """PointCloud2-style rows held in a numpy uint8 buffer."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        if data.size < n_points * point_step:
+            raise ValueError("row buffer smaller than n_points*point_step")
+        c = Cloud(data.ctypes.data, n_points, point_step, offsets[0], offsets[1], offsets[2],
+                  GM_CLOUD_BIGENDIAN if bigendian else 0)
+        return c, data
+
+    @staticmethod
+    def cloud_from_device(ptr, n_points, point_step=16, offsets=(0, 4, 8)):
+        """Rows already resident in this device's HBM (e.g. a torch tensor's data_ptr())."""
+        return Cloud(int(ptr), n_points, point_step, offsets[0], offsets[1], offsets[2], GM_CLOUD_DEVICE), None
+
+    def _as_cloud(self, cloud):
+        if isinstance(cloud, tuple) and isinstance(cloud[0], Cloud):
+            return cloud
+        return self._cloud_from_xyz(cloud)
+
+    @staticmethod
+    def _result(res):
+        ev = np.array(res.eigenvalues[:], dtype=np.float32)
+        V = np.array(res.eigenvectors[:], dtype=np.float32).reshape(3, 3).T.copy()  # column-major -> [row, col]
+        sc = np.array(res.scatter[:], dtype=np.float64)
+        M = np.array([[sc[0], sc[1], sc[2]], [sc[1], sc[3], sc[4]], [sc[2], sc[4], sc[5]]])
+        return dict(n_in=res.n_in, n_cropped=res.n_cropped, n_valid=res.n_valid, n_voxels=res.n_voxels,
+                    eigenvalues=ev, eigenvectors=V, center_axis=np.array(res.center_axis[:], dtype=np.float32),
+                    scatter=M, scatter6=sc, status_flags=res.status_flags,
+                    stage_ms={k: float(res.stage_ms[i]) for i, k in enumerate(STAGE_NAMES)},
+                    normals_kernel_ms=float(res.normals_kernel_ms),
+                    plane=np.array(res.plane[:], dtype=np.float32), cylinder=np.array(res.cylinder[:], dtype=np.float32),
+                    plane_inliers=res.plane_inliers, cylinder_inliers=res.cylinder_inliers,
+                    plane_refit=np.array(res.plane_refit[:]), cylinder_axis_refit=np.array(res.cylinder_axis_refit[:]))
+
+    # ---- the callback: src/geometric_mapping.cpp:55-92 ----
+    def process_frame(self, cloud):
+        c, keep = self._as_cloud(cloud)
+        res = FrameResult()
+        self._check(self._L.gm_process_frame(self._ctx, C.byref(c), C.byref(res)))
+        return self._result(res)
+
+    def submit_frame(self, slot, cloud):
+        c, keep = self._as_cloud(cloud)
+        self._check(self._L.gm_submit_frame(self._ctx, slot, C.byref(c)))
+
+    def wait_frame(self, slot):
+        res = FrameResult()
+        self._check(self._L.gm_wait_frame(self._ctx, slot, C.byref(res)))
+        return self._result(res)
+
+    def _fetch(self, fn, slot, width, dtype=np.float32):
+        n = C.c_uint32(0)
+        st = fn(self._ctx, slot, None, 0, C.byref(n))
+        if st not in (GM_OK, GM_ERR_CAPACITY):
+            self._check(st)
+        out = np.empty((n.value, width) if width > 1 else (n.value,), dtype=dtype)
+        if n.value:
+            ptr = out.ctypes.data_as(fn.argtypes[2])
+            self._check(fn(self._ctx, slot, ptr, n.value, C.byref(n)))
+        return out
+
+    def cropped_cloud(self, slot=0):
+        """/choppedCloud: (xyz [n,3], input row index [n])."""
+        a = self._fetch(self._L.gm_get_cropped_xyz, slot, 4)
+        return a[:, :3].copy(), a[:, 3].copy().view(np.int32)
+
+    def normals(self, slot=0):
+        return self._fetch(self._L.gm_get_normals, slot, 4)
+
+    def voxel_centroids(self, slot=0):
+        """(centroids [V,3], points per voxel [V]) in ascending voxel-key order."""
+        a = self._fetch(self._L.gm_get_voxel_centroids, slot, 4)
+        return a[:, :3].copy(), a[:, 3].astype(np.int32)
+
+    def neighbor_counts(self, slot=0):
+        return self._fetch(self._L.gm_get_neighbor_counts, slot, 1, np.int32)
+
+    def set_owned_range(self, lo, hi):
+        self._check(self._L.gm_set_owned_range(self._ctx, float(lo), float(hi)))
+
+    # ---- the reference's stage functions (tunnel_processing.hpp) ----
+    def chopCloud(self, bound, cloud):
+        """tunnel_processing.hpp:38.  Returns (cloudChopped [n',3], kept input rows [n'])."""
+        c, keep = self._as_cloud(cloud)
+        cap = max(c.n_points, 1)
+        out = np.empty((cap, 4), dtype=np.float32)
+        n = C.c_uint32(0)
+        self._check(self._L.gm_chop_cloud(self._ctx, C.byref(c), float(bound), _f32(out), cap, C.byref(n)))
+        out = out[:n.value]
+        return out[:, :3].copy(), out[:, 3].copy().view(np.int32)
+
+    def getNormals(self, neighborRadius, cloud):
+        """tunnel_processing.hpp:41-45.  The reference compacts `cloud` in place and
+        returns the normals; here both come back: (normals [n'',4], cloud [n'',3], kept rows [n''])."""
+        xyz = np.ascontiguousarray(cloud, dtype=np.float32)
+        if xyz.ndim != 2 or xyz.shape[1] != 3:
+            raise ValueError("cloud must be [n,3]")
+        n0 = xyz.shape[0]
+        cap = max(n0, 1)
+        oc = np.empty((cap, 4), dtype=np.float32)
+        on = np.empty((cap, 4), dtype=np.float32)
+        n = C.c_uint32(0)
+        self._check(self._L.gm_get_normals_stage(self._ctx, _f32(xyz), n0, float(neighborRadius), _f32(oc), _f32(on),
+                                                 cap, C.byref(n)))
+        oc, on = oc[:n.value], on[:n.value]
+        return on.copy(), oc[:, :3].copy(), oc[:, 3].copy().view(np.int32)
+
+    def getLocalFrame(self, cloudSize, weightingFactor, cloud_normals):
+        """tunnel_processing.hpp:48-54.  Returns (eigenVals [3] ascending, eigenVecs [3,3] columns, M [3,3] fp64)."""
+        nrm = np.ascontiguousarray(cloud_normals, dtype=np.float32)
+        if nrm.ndim != 2 or nrm.shape[1] != 4:
+            raise ValueError("normals must be [n,4] (nx,ny,nz,curvature)")
+        if cloudSize > nrm.shape[0]:
+            raise ValueError("cloudSize exceeds the normals cloud (the reference's .at() would throw)")
+        ev = np.zeros(3, dtype=np.float32)
+        V = np.zeros(9, dtype=np.float32)
+        sc = np.zeros(6, dtype=np.float64)
+        self._check(self._L.gm_get_local_frame(self._ctx, _f32(nrm), int(cloudSize), float(weightingFactor), _f32(ev),
+                                               _f32(V), sc.ctypes.data_as(C.POINTER(C.c_double))))
+        M = np.array([[sc[0], sc[1], sc[2]], [sc[1], sc[3], sc[4]], [sc[2], sc[4], sc[5]]])
+        return ev, V.reshape(3, 3).T.copy(), M
+
+    def voxelGrid(self, leafSize, cloud):
+        """The pcl::VoxelGrid half of rvizNormals (tunnel_processing.hpp:77-82).
+        Returns (centroids [V,3], counts [V], passthrough flag)."""
+        xyz = np.ascontiguousarray(cloud, dtype=np.float32)
+        if xyz.ndim != 2 or xyz.shape[1] != 3:
+            raise ValueError("cloud must be [n,3]")
+        cap = max(xyz.shape[0], 1)
+        out = np.empty((cap, 4), dtype=np.float32)
+        n = C.c_uint32(0)
+        fl = C.c_uint32(0)
+        self._check(self._L.gm_voxel_grid(self._ctx, _f32(xyz), xyz.shape[0], float(leafSize), _f32(out), cap,
+                                          C.byref(n), C.byref(fl)))
+        out = out[:n.value]
+        return out[:, :3].copy(), out[:, 3].astype(np.int32), bool(fl.value & _lib.GM_RES_VOXEL_PASSTHROUGH)
+
+
+def solve_local_frame(scatter6):
+    """Eigen-solve a merged scatter matrix (multi-GPU merge unit)."""
+    L = _lib.load()
+    sc = np.ascontiguousarray(scatter6, dtype=np.float64)
+    ev = np.zeros(3, dtype=np.float32)
+    V = np.zeros(9, dtype=np.float32)
+    st = L.gm_solve_local_frame(sc.ctypes.data_as(C.POINTER(C.c_double)), _f32(ev), _f32(V))
+    if st != GM_OK:
+        raise GmError(st, "gm_solve_local_frame")
+    return ev, V.reshape(3, 3).T.copy()

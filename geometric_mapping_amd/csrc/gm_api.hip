@@ -1,0 +1,623 @@
+// gm_api.hip -- the C ABI of include/gm_hip.h: context, slots, the per-frame
+// pipeline and the stage-level entry points.  Host logic only; kernels live in
+// the k_*.hip files.  No exception crosses the ABI.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <limits>
+#include <new>
+
+#include "gm_compact.hpp"
+#include "gm_internal.hpp"
+
+using namespace gm;
+
+namespace {
+
+thread_local std::string g_create_err;
+
+#define GM_HIP(ctx, call)                                                                 \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);              \
+            return (e__ == hipErrorOutOfMemory) ? GM_ERR_OOM : GM_ERR_DEVICE;             \
+        }                                                                                 \
+    } while (0)
+
+gm_status fail(gm_ctx *ctx, gm_status st, const char *msg)
+{
+    if (ctx) ctx->err = msg; else g_create_err = msg;
+    return st;
+}
+
+template <class T>
+hipError_t dmalloc(T *&p, size_t count)
+{
+    p = nullptr;
+    return hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
+}
+
+void free_slot_buffers(Slot &sl)
+{
+    hipFree(sl.d_raw); hipFree(sl.crop4); hipFree(sl.keys_a); hipFree(sl.keys_b); hipFree(sl.vals_a);
+    hipFree(sl.vals_b); hipFree(sl.spts4); hipFree(sl.normals4); hipFree(sl.counts); hipFree(sl.valid4);
+    hipFree(sl.vnorm4); hipFree(sl.tiles); hipFree(sl.blk); hipFree(sl.sort.hist); hipFree(sl.seg_start);
+    hipFree(sl.vox4); hipFree(sl.vox_nn); hipFree(sl.labels);
+    if (sl.h_raw) hipHostFree(sl.h_raw);
+    sl.d_raw = nullptr; sl.h_raw = nullptr; sl.crop4 = nullptr; sl.keys_a = sl.keys_b = sl.vals_a = sl.vals_b = nullptr;
+    sl.spts4 = sl.normals4 = sl.valid4 = sl.vnorm4 = sl.vox4 = nullptr; sl.counts = nullptr; sl.tiles = nullptr;
+    sl.blk = nullptr; sl.sort.hist = nullptr; sl.seg_start = nullptr; sl.vox_nn = nullptr; sl.labels = nullptr;
+    sl.cap = 0; sl.raw_cap = 0; sl.tiles_cap = 0;
+}
+
+// search grid over the crop box [-b, b]^3 (cell edge >= 1.001 r, <= 1024 cells per axis)
+GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, float ez, double radius)
+{
+    GridParams g;
+    float ext = fmaxf(ex, fmaxf(ey, ez));
+    float h = (float)radius * 1.001f;
+    if (!(h > 1e-9f)) h = 1e-9f;
+    if (h < ext / 1023.0f) h = ext / 1023.0f;
+    g.ox = lo_x; g.oy = lo_y; g.oz = lo_z;
+    g.inv_h = 1.0f / h;
+    auto dim = [&](float e) { int n = (int)floorf(e * g.inv_h) + 1; return n < 1 ? 1 : (n > 1024 ? 1024 : n); };
+    g.nx = dim(ex); g.ny = dim(ey); g.nz = dim(ez);
+    g.r2 = (float)(radius * radius);  // KdTreeFLANN::radiusSearch: static_cast<float>(radius*radius)
+    return g;
+}
+
+int bits_for(uint64_t count)
+{
+    int b = 1;
+    while ((1ull << b) < count && b < 32) ++b;
+    return b;
+}
+
+// upper bound of VoxelGrid's dx*dy*dz for points inside [lo,hi]^3 -> sort key bits
+int voxel_key_bits(double lo, double hi, double leaf)
+{
+    const float inv = 1.0f / (float)leaf;
+    double d = floor((double)((float)hi * inv)) - floor((double)((float)lo * inv)) + 2.0;
+    if (!(d > 0) || !std::isfinite(d)) return 32;
+    double prod = d * d * d;
+    if (prod > 2147483647.0) return 32;  // may hit PCL's overflow guard: keys become row indices
+    return bits_for((uint64_t)prod);
+}
+
+gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, bool need_raw)
+{
+    if (need_raw && raw_bytes > sl.raw_cap) {
+        if (sl.h_raw) hipHostFree(sl.h_raw);
+        hipFree(sl.d_raw);
+        sl.h_raw = nullptr; sl.d_raw = nullptr;
+        size_t cap = raw_bytes + raw_bytes / 4 + 4096;
+        GM_HIP(ctx, hipHostMalloc((void **)&sl.h_raw, cap, hipHostMallocDefault));
+        GM_HIP(ctx, hipMalloc((void **)&sl.d_raw, cap));
+        sl.raw_cap = cap;
+    }
+    if (n <= sl.cap) return GM_OK;
+    GM_HIP(ctx, hipStreamSynchronize(sl.stream));
+    uint8_t *h_raw = sl.h_raw, *d_raw = sl.d_raw; size_t raw_cap = sl.raw_cap;
+    sl.h_raw = nullptr; sl.d_raw = nullptr;
+    free_slot_buffers(sl);
+    sl.h_raw = h_raw; sl.d_raw = d_raw; sl.raw_cap = raw_cap;
+    uint32_t cap = n + n / 4 + 1024;
+    if (cap < ctx->cfg.max_points) cap = ctx->cfg.max_points;
+    GM_HIP(ctx, dmalloc(sl.crop4, cap));
+    GM_HIP(ctx, dmalloc(sl.keys_a, cap)); GM_HIP(ctx, dmalloc(sl.keys_b, cap));
+    GM_HIP(ctx, dmalloc(sl.vals_a, cap)); GM_HIP(ctx, dmalloc(sl.vals_b, cap));
+    GM_HIP(ctx, dmalloc(sl.spts4, cap)); GM_HIP(ctx, dmalloc(sl.normals4, cap));
+    GM_HIP(ctx, dmalloc(sl.counts, cap));
+    GM_HIP(ctx, dmalloc(sl.valid4, cap)); GM_HIP(ctx, dmalloc(sl.vnorm4, cap));
+    GM_HIP(ctx, dmalloc(sl.seg_start, cap)); GM_HIP(ctx, dmalloc(sl.vox4, cap));
+    GM_HIP(ctx, dmalloc(sl.vox_nn, cap)); GM_HIP(ctx, dmalloc(sl.labels, cap));
+    sl.tiles_cap = cap / kWave + 1024u * 1024u + 2u;  // n/64 + at most 1024*1024 x-rows
+    if (sl.tiles_cap > cap + cap / kWave + 2u) sl.tiles_cap = cap + cap / kWave + 2u;
+    GM_HIP(ctx, dmalloc(sl.tiles, sl.tiles_cap));
+    sl.blk_cap = compact_blocks(cap) + 1;
+    GM_HIP(ctx, dmalloc(sl.blk, sl.blk_cap));
+    sl.sort.hist_cap = radix_hist_entries(cap);
+    GM_HIP(ctx, dmalloc(sl.sort.hist, sl.sort.hist_cap));
+    sl.cap = cap;
+    return GM_OK;
+}
+
+gm_status make_rows(gm_ctx *ctx, const gm_cloud *c, const uint8_t *dev_data, RowLayout &rows)
+{
+    if (c->n_points && (c->point_step < 12 || c->off_x + 4 > c->point_step || c->off_y + 4 > c->point_step ||
+                        c->off_z + 4 > c->point_step))
+        return fail(ctx, GM_ERR_INVALID_ARG, "gm_cloud: x/y/z offsets do not fit in point_step");
+    rows.data = dev_data;
+    rows.step = c->point_step; rows.ox = c->off_x; rows.oy = c->off_y; rows.oz = c->off_z;
+    rows.bswap = (c->flags & GM_CLOUD_BIGENDIAN) ? 1u : 0u;
+    const bool al4 = ((c->point_step | c->off_x | c->off_y | c->off_z) & 3u) == 0 && (((uintptr_t)dev_data) & 3u) == 0;
+    const bool al16 = al4 && c->point_step == 16 && c->off_x == 0 && c->off_y == 4 && c->off_z == 8 &&
+                      (((uintptr_t)dev_data) & 15u) == 0;
+    rows.mode = al16 ? 0u : (al4 ? 1u : 2u);
+    return GM_OK;
+}
+
+void record(gm_ctx *ctx, Slot &sl, int idx)
+{
+    if (ctx->cfg.flags & GM_CFG_STAGE_TIMING) hipEventRecord(sl.ev[idx], sl.stream);
+}
+
+gm_status reset_counters(gm_ctx *ctx, Slot &sl)
+{
+    GM_HIP(ctx, hipMemsetAsync(sl.ctr, 0, sizeof(DevCounters), sl.stream));
+    return GM_OK;
+}
+
+gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud)
+{
+    const uint32_t n = cloud->n_points;
+    const size_t raw_bytes = (size_t)n * cloud->point_step;
+    const bool on_dev = (cloud->flags & GM_CLOUD_DEVICE) != 0;
+    if (n && !cloud->data) return fail(ctx, GM_ERR_INVALID_ARG, "gm_cloud.data is NULL");
+    gm_status st = ensure_capacity(ctx, sl, n, raw_bytes, !on_dev);
+    if (st != GM_OK) return st;
+    hipStream_t s = sl.stream;
+    sl.n_in = n;
+    st = reset_counters(ctx, sl);
+    if (st != GM_OK) return st;
+    record(ctx, sl, 0);
+    const uint8_t *dev_rows = (const uint8_t *)cloud->data;
+    if (!on_dev && n) {
+        memcpy(sl.h_raw, cloud->data, raw_bytes);  // pinned staging: the caller's buffer is free again on return
+        GM_HIP(ctx, hipMemcpyAsync(sl.d_raw, sl.h_raw, raw_bytes, hipMemcpyHostToDevice, s));
+        dev_rows = sl.d_raw;
+    }
+    record(ctx, sl, 1);
+    RowLayout rows;
+    st = make_rows(ctx, cloud, dev_rows, rows);
+    if (st != GM_OK) return st;
+    const gm_config &cf = ctx->cfg;
+    // Eigen::Vector4f(-bound, ...) : double -> float (src/tunnel_processing.cpp:43-44)
+    const float lo = (float)(-cf.boxFilterBound), hi = (float)cf.boxFilterBound;
+    const float ext = hi - lo;
+    const GridParams g = make_grid(lo, lo, lo, ext, ext, ext, cf.neighborRadius);
+    launch_crop(rows, n, lo, hi, g, sl, s);
+    record(ctx, sl, 2);
+    launch_grid_and_normals(g, sl, n, (cf.flags & GM_CFG_KEEP_COUNTS) != 0, s);
+    record(ctx, sl, 3);  // end of grid+normals; the kernel alone is bracketed by ev_k0/ev_k1
+    launch_compact_valid(sl, n, (float)ctx->own_lo, (float)ctx->own_hi, s);
+    record(ctx, sl, 4);
+    const uint32_t nparts = launch_scatter_partials(sl.vnorm4, &sl.ctr->n_valid, n, cf.weightingFactor, sl, s);
+    record(ctx, sl, 5);
+    if (cf.flags & GM_CFG_VOXEL_GRID) {
+        launch_minmax(sl.valid4, &sl.ctr->n_valid, n, sl.ctr, s);
+        launch_voxel_grid(sl, n, (float)cf.voxelGridLeafSize, voxel_key_bits(lo, hi, cf.voxelGridLeafSize), s);
+    }
+    record(ctx, sl, 6);
+    launch_frame_finalize(nparts, sl, s);
+    GM_HIP(ctx, hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(FrameOut), hipMemcpyDeviceToHost, s));
+    record(ctx, sl, 7);
+    GM_HIP(ctx, hipGetLastError());
+    sl.submitted = true;
+    sl.complete = false;
+    return GM_OK;
+}
+
+void fill_result(gm_ctx *ctx, Slot &sl, gm_frame_result *r)
+{
+    memset(r, 0, sizeof(*r));
+    const FrameOut &o = *sl.h_out;
+    r->n_in = sl.n_in;
+    r->n_cropped = o.ctr.n_cropped;
+    r->n_valid = o.ctr.n_valid;
+    r->n_voxels = (ctx->cfg.flags & GM_CFG_VOXEL_GRID) ? o.ctr.n_voxels : 0;
+    for (int k = 0; k < 3; ++k) r->eigenvalues[k] = o.evals[k];
+    for (int k = 0; k < 9; ++k) r->eigenvectors[k] = o.evecs[k];
+    for (int k = 0; k < 3; ++k) r->center_axis[k] = o.evecs[k];  // block<3,1>(0,0)
+    for (int k = 0; k < 6; ++k) r->scatter[k] = o.scatter[k];
+    if ((ctx->cfg.flags & GM_CFG_VOXEL_GRID) && o.vox.passthrough) r->status_flags |= GM_RES_VOXEL_PASSTHROUGH;
+    float ms = 0;
+    if (sl.n_in && hipEventElapsedTime(&ms, sl.ev_k0, sl.ev_k1) == hipSuccess) r->normals_kernel_ms = ms;
+    if (ctx->cfg.flags & GM_CFG_STAGE_TIMING) {
+        static const int stage_of[7] = {GM_STAGE_UPLOAD, GM_STAGE_CROP, GM_STAGE_NORMALS, GM_STAGE_COMPACT,
+                                        GM_STAGE_FRAME, GM_STAGE_VOXEL, GM_STAGE_FRAME};
+        for (int i = 0; i < 7; ++i)
+            if (hipEventElapsedTime(&ms, sl.ev[i], sl.ev[i + 1]) == hipSuccess) r->stage_ms[stage_of[i]] += ms;
+        if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[7]) == hipSuccess) r->stage_ms[GM_STAGE_TOTAL] = ms;
+        r->stage_ms[GM_STAGE_GRID] = r->stage_ms[GM_STAGE_NORMALS] - r->normals_kernel_ms;
+        r->stage_ms[GM_STAGE_NORMALS] = r->normals_kernel_ms;
+    }
+}
+
+gm_status wait_slot(gm_ctx *ctx, Slot &sl)
+{
+    if (!sl.submitted) return fail(ctx, GM_ERR_NOT_READY, "slot has no submitted frame");
+    if (!sl.complete) {
+        GM_HIP(ctx, hipStreamSynchronize(sl.stream));
+        fill_result(ctx, sl, &sl.last);
+        sl.complete = true;
+    }
+    return GM_OK;
+}
+
+template <class T>
+gm_status fetch(gm_ctx *ctx, uint32_t slot, const T *dev, uint32_t avail, T *out, uint32_t capacity, uint32_t *n_out)
+{
+    if (n_out) *n_out = avail;
+    if (avail > capacity) return fail(ctx, GM_ERR_CAPACITY, "output buffer too small");
+    if (avail == 0) return GM_OK;
+    if (!out) return fail(ctx, GM_ERR_INVALID_ARG, "output pointer is NULL");
+    Slot &sl = ctx->slots[slot];
+    GM_HIP(ctx, hipMemcpyAsync(out, dev, (size_t)avail * sizeof(T), hipMemcpyDeviceToHost, sl.stream));
+    GM_HIP(ctx, hipStreamSynchronize(sl.stream));
+    return GM_OK;
+}
+
+gm_status check_slot(gm_ctx *ctx, uint32_t slot)
+{
+    if (!ctx) return GM_ERR_INVALID_ARG;
+    if (slot >= ctx->n_slots) return fail(ctx, GM_ERR_INVALID_ARG, "slot out of range");
+    gm_status st = hipSetDevice(ctx->device) == hipSuccess ? GM_OK : GM_ERR_DEVICE;
+    if (st != GM_OK) return fail(ctx, st, "hipSetDevice failed");
+    return wait_slot(ctx, ctx->slots[slot]);
+}
+
+// stage calls reuse slot 0 and leave it "not submitted"
+gm_status begin_stage(gm_ctx *ctx, Slot *&sl)
+{
+    if (!ctx) return GM_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, GM_ERR_DEVICE, "hipSetDevice failed");
+    sl = &ctx->slots[0];
+    GM_HIP(ctx, hipStreamSynchronize(sl->stream));
+    sl->submitted = false;
+    sl->complete = false;
+    return GM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t gm_abi_version(void) { return GM_ABI_VERSION; }
+
+const char *gm_status_string(gm_status s)
+{
+    switch (s) {
+    case GM_OK: return "ok";
+    case GM_ERR_INVALID_ARG: return "invalid argument";
+    case GM_ERR_TOO_FEW_POINTS: return "too few points";
+    case GM_ERR_DEVICE: return "device error";
+    case GM_ERR_OOM: return "out of memory";
+    case GM_ERR_CAPACITY: return "output capacity too small";
+    case GM_ERR_NOT_READY: return "not ready";
+    case GM_ERR_UNSUPPORTED: return "unsupported";
+    }
+    return "unknown";
+}
+
+const char *gm_last_error(const gm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+void gm_default_config(gm_config *cfg)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = sizeof(gm_config);
+    cfg->flags = GM_CFG_DEFAULT;
+    cfg->boxFilterBound = 5.0;     // launch/mapping.launch:7
+    cfg->voxelGridLeafSize = 0.5;  // :8
+    cfg->neighborRadius = 0.5;     // :9
+    cfg->weightingFactor = 0.2;    // :10
+    cfg->device = 0;
+    cfg->n_slots = 1;
+    cfg->max_points = 0;
+    cfg->ransac_hypotheses = 1024;
+    cfg->ransac_threshold = 0.03;
+    cfg->ransac_seed = 1;
+}
+
+gm_status gm_create(const gm_config *cfg, gm_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, GM_ERR_INVALID_ARG, "gm_create: NULL argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(gm_config)) return fail(nullptr, GM_ERR_INVALID_ARG, "gm_config.struct_size mismatch");
+    if (!(cfg->weightingFactor != 0.0) || !std::isfinite(cfg->boxFilterBound) || !(cfg->boxFilterBound >= 0.0) ||
+        !(cfg->voxelGridLeafSize > 0.0) || !(cfg->neighborRadius >= 0.0))
+        return fail(nullptr, GM_ERR_INVALID_ARG, "gm_config: bad numeric parameter");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, GM_ERR_DEVICE, "no HIP device visible (libgm_hip has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, GM_ERR_INVALID_ARG, "gm_config.device out of range");
+    gm_ctx *ctx = new (std::nothrow) gm_ctx();
+    if (!ctx) return fail(nullptr, GM_ERR_OOM, "host allocation failed");
+    ctx->cfg = *cfg;
+    ctx->device = cfg->device;
+    ctx->n_slots = cfg->n_slots ? cfg->n_slots : 1;
+    if (ctx->n_slots > 16) ctx->n_slots = 16;
+    ctx->own_lo = -std::numeric_limits<double>::infinity();
+    ctx->own_hi = std::numeric_limits<double>::infinity();
+    gm_status st = GM_OK;
+    auto body = [&]() -> gm_status {
+        GM_HIP(ctx, hipSetDevice(ctx->device));
+        hipDeviceProp_t prop;
+        GM_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            ctx->err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+            return GM_ERR_DEVICE;
+        }
+        ctx->slots = new (std::nothrow) Slot[ctx->n_slots];
+        if (!ctx->slots) return GM_ERR_OOM;
+        for (uint32_t i = 0; i < ctx->n_slots; ++i) {
+            Slot &sl = ctx->slots[i];
+            GM_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+            for (int k = 0; k <= GM_N_STAGES; ++k) GM_HIP(ctx, hipEventCreate(&sl.ev[k]));
+            GM_HIP(ctx, hipEventCreate(&sl.ev_k0));
+            GM_HIP(ctx, hipEventCreate(&sl.ev_k1));
+            GM_HIP(ctx, dmalloc(sl.ctr, 1));
+            GM_HIP(ctx, dmalloc(sl.voxp, 1));
+            GM_HIP(ctx, dmalloc(sl.d_out, 1));
+            GM_HIP(ctx, dmalloc(sl.partials, (size_t)kScatterBlocks * 6));
+            GM_HIP(ctx, hipHostMalloc((void **)&sl.h_out, sizeof(FrameOut), hipHostMallocDefault));
+            GM_HIP(ctx, hipMemset(sl.voxp, 0, sizeof(VoxelParams)));
+            GM_HIP(ctx, hipMemset(sl.d_out, 0, sizeof(FrameOut)));
+            memset(sl.h_out, 0, sizeof(FrameOut));
+            if (cfg->max_points) {
+                gm_status s2 = ensure_capacity(ctx, sl, cfg->max_points, 0, false);
+                if (s2 != GM_OK) return s2;
+            }
+        }
+        return GM_OK;
+    };
+    st = body();
+    if (st != GM_OK) {
+        g_create_err = ctx->err;
+        gm_destroy(ctx);
+        return st;
+    }
+    *out = ctx;
+    return GM_OK;
+}
+
+void gm_destroy(gm_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->slots) {
+        for (uint32_t i = 0; i < ctx->n_slots; ++i) {
+            Slot &sl = ctx->slots[i];
+            if (sl.stream) hipStreamSynchronize(sl.stream);
+            free_slot_buffers(sl);
+            hipFree(sl.ctr); hipFree(sl.voxp); hipFree(sl.d_out); hipFree(sl.partials);
+            hipFree(sl.hyp); hipFree(sl.hyp_counts); hipFree(sl.seg_mom);
+            if (sl.h_out) hipHostFree(sl.h_out);
+            for (int k = 0; k <= GM_N_STAGES; ++k) if (sl.ev[k]) hipEventDestroy(sl.ev[k]);
+            if (sl.ev_k0) hipEventDestroy(sl.ev_k0);
+            if (sl.ev_k1) hipEventDestroy(sl.ev_k1);
+            if (sl.stream) hipStreamDestroy(sl.stream);
+        }
+        delete[] ctx->slots;
+    }
+    delete ctx;
+}
+
+gm_status gm_set_owned_range(gm_ctx *ctx, double own_lo, double own_hi)
+{
+    if (!ctx) return GM_ERR_INVALID_ARG;
+    if (!(own_lo <= own_hi)) return fail(ctx, GM_ERR_INVALID_ARG, "owned range is empty or NaN");
+    ctx->own_lo = own_lo;
+    ctx->own_hi = own_hi;
+    return GM_OK;
+}
+
+gm_status gm_submit_frame(gm_ctx *ctx, uint32_t slot, const gm_cloud *cloud)
+{
+    if (!ctx || !cloud) return GM_ERR_INVALID_ARG;
+    if (slot >= ctx->n_slots) return fail(ctx, GM_ERR_INVALID_ARG, "slot out of range");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, GM_ERR_DEVICE, "hipSetDevice failed");
+    Slot &sl = ctx->slots[slot];
+    if (sl.submitted && !sl.complete) {  // previous frame of this slot still owns the buffers
+        GM_HIP(ctx, hipStreamSynchronize(sl.stream));
+    }
+    sl.submitted = false;
+    return enqueue_frame(ctx, sl, cloud);
+}
+
+gm_status gm_wait_frame(gm_ctx *ctx, uint32_t slot, gm_frame_result *res)
+{
+    gm_status st = check_slot(ctx, slot);
+    if (st != GM_OK) return st;
+    if (res) *res = ctx->slots[slot].last;
+    return GM_OK;
+}
+
+gm_status gm_process_frame(gm_ctx *ctx, const gm_cloud *cloud, gm_frame_result *res)
+{
+    gm_status st = gm_submit_frame(ctx, 0, cloud);
+    if (st != GM_OK) return st;
+    return gm_wait_frame(ctx, 0, res);
+}
+
+gm_status gm_get_cropped_xyz(gm_ctx *ctx, uint32_t slot, float *xyzw, uint32_t capacity, uint32_t *n_out)
+{
+    gm_status st = check_slot(ctx, slot);
+    if (st != GM_OK) return st;
+    Slot &sl = ctx->slots[slot];
+    return fetch(ctx, slot, (const float4 *)sl.valid4, sl.last.n_valid, (float4 *)xyzw, capacity, n_out);
+}
+
+gm_status gm_get_normals(gm_ctx *ctx, uint32_t slot, float *nxyzc, uint32_t capacity, uint32_t *n_out)
+{
+    gm_status st = check_slot(ctx, slot);
+    if (st != GM_OK) return st;
+    Slot &sl = ctx->slots[slot];
+    return fetch(ctx, slot, (const float4 *)sl.vnorm4, sl.last.n_valid, (float4 *)nxyzc, capacity, n_out);
+}
+
+gm_status gm_get_voxel_centroids(gm_ctx *ctx, uint32_t slot, float *xyzc, uint32_t capacity, uint32_t *n_out)
+{
+    gm_status st = check_slot(ctx, slot);
+    if (st != GM_OK) return st;
+    Slot &sl = ctx->slots[slot];
+    if (!(ctx->cfg.flags & GM_CFG_VOXEL_GRID)) return fail(ctx, GM_ERR_NOT_READY, "context created without GM_CFG_VOXEL_GRID");
+    return fetch(ctx, slot, (const float4 *)sl.vox4, sl.last.n_voxels, (float4 *)xyzc, capacity, n_out);
+}
+
+gm_status gm_get_neighbor_counts(gm_ctx *ctx, uint32_t slot, int32_t *counts, uint32_t capacity, uint32_t *n_out)
+{
+    gm_status st = check_slot(ctx, slot);
+    if (st != GM_OK) return st;
+    Slot &sl = ctx->slots[slot];
+    if (!(ctx->cfg.flags & GM_CFG_KEEP_COUNTS)) return fail(ctx, GM_ERR_NOT_READY, "context created without GM_CFG_KEEP_COUNTS");
+    return fetch(ctx, slot, (const int32_t *)sl.counts, sl.last.n_cropped, counts, capacity, n_out);
+}
+
+// ---- stage-level entry points -----------------------------------------------------
+
+gm_status gm_chop_cloud(gm_ctx *ctx, const gm_cloud *cloud, double bound, float *xyzw_out, uint32_t capacity,
+                        uint32_t *n_out)
+{
+    Slot *slp;
+    gm_status st = begin_stage(ctx, slp);
+    if (st != GM_OK) return st;
+    if (!cloud) return fail(ctx, GM_ERR_INVALID_ARG, "cloud is NULL");
+    if (!std::isfinite(bound) || bound < 0) return fail(ctx, GM_ERR_INVALID_ARG, "bound must be finite and >= 0");
+    Slot &sl = *slp;
+    const uint32_t n = cloud->n_points;
+    const size_t raw_bytes = (size_t)n * cloud->point_step;
+    const bool on_dev = (cloud->flags & GM_CLOUD_DEVICE) != 0;
+    if (n && !cloud->data) return fail(ctx, GM_ERR_INVALID_ARG, "gm_cloud.data is NULL");
+    st = ensure_capacity(ctx, sl, n, raw_bytes, !on_dev);
+    if (st != GM_OK) return st;
+    st = reset_counters(ctx, sl);
+    if (st != GM_OK) return st;
+    const uint8_t *dev_rows = (const uint8_t *)cloud->data;
+    if (!on_dev && n) {
+        memcpy(sl.h_raw, cloud->data, raw_bytes);
+        GM_HIP(ctx, hipMemcpyAsync(sl.d_raw, sl.h_raw, raw_bytes, hipMemcpyHostToDevice, sl.stream));
+        dev_rows = sl.d_raw;
+    }
+    RowLayout rows;
+    st = make_rows(ctx, cloud, dev_rows, rows);
+    if (st != GM_OK) return st;
+    const float lo = (float)(-bound), hi = (float)bound;
+    const GridParams g = make_grid(lo, lo, lo, hi - lo, hi - lo, hi - lo, ctx->cfg.neighborRadius);
+    launch_crop(rows, n, lo, hi, g, sl, sl.stream);
+    uint32_t m = 0;
+    GM_HIP(ctx, hipMemcpyAsync(&m, &sl.ctr->n_cropped, 4, hipMemcpyDeviceToHost, sl.stream));
+    GM_HIP(ctx, hipStreamSynchronize(sl.stream));
+    return fetch(ctx, 0, (const float4 *)sl.crop4, m, (float4 *)xyzw_out, capacity, n_out);
+}
+
+gm_status gm_get_normals_stage(gm_ctx *ctx, const float *xyz, uint32_t n, double radius, float *xyzw_out,
+                               float *nxyzc_out, uint32_t capacity, uint32_t *n_out)
+{
+    Slot *slp;
+    gm_status st = begin_stage(ctx, slp);
+    if (st != GM_OK) return st;
+    if (n && !xyz) return fail(ctx, GM_ERR_INVALID_ARG, "xyz is NULL");
+    if (!(radius >= 0.0) || !std::isfinite(radius)) return fail(ctx, GM_ERR_INVALID_ARG, "radius must be finite and >= 0");
+    Slot &sl = *slp;
+    const size_t raw_bytes = (size_t)n * 12;
+    st = ensure_capacity(ctx, sl, n, raw_bytes, true);
+    if (st != GM_OK) return st;
+    st = reset_counters(ctx, sl);
+    if (st != GM_OK) return st;
+    // extents of the finite rows fix the search grid (the frame path knows them from the crop box)
+    float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *p = xyz + 3 * (size_t)i;
+        if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;
+        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], p[k]); mx[k] = fmaxf(mx[k], p[k]); }
+    }
+    if (mn[0] > mx[0]) { for (int k = 0; k < 3; ++k) { mn[k] = 0; mx[k] = 0; } }
+    if (n) {
+        memcpy(sl.h_raw, xyz, raw_bytes);
+        GM_HIP(ctx, hipMemcpyAsync(sl.d_raw, sl.h_raw, raw_bytes, hipMemcpyHostToDevice, sl.stream));
+    }
+    gm_cloud c = {sl.d_raw, n, 12, 0, 4, 8, GM_CLOUD_DEVICE};
+    RowLayout rows;
+    st = make_rows(ctx, &c, sl.d_raw, rows);
+    if (st != GM_OK) return st;
+    const GridParams g = make_grid(mn[0], mn[1], mn[2], mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], radius);
+    const float big = std::numeric_limits<float>::max();
+    launch_crop(rows, n, -big, big, g, sl, sl.stream);  // drops non-finite rows only
+    launch_grid_and_normals(g, sl, n, (ctx->cfg.flags & GM_CFG_KEEP_COUNTS) != 0, sl.stream);
+    launch_compact_valid(sl, n, -std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity(), sl.stream);
+    uint32_t m[2] = {0, 0};
+    GM_HIP(ctx, hipMemcpyAsync(m, &sl.ctr->n_cropped, 8, hipMemcpyDeviceToHost, sl.stream));
+    GM_HIP(ctx, hipStreamSynchronize(sl.stream));
+    GM_HIP(ctx, hipGetLastError());
+    sl.last.n_cropped = m[0];
+    sl.last.n_valid = m[1];
+    sl.submitted = true;  // accessors (neighbour counts) may read this slot
+    sl.complete = true;
+    st = fetch(ctx, 0, (const float4 *)sl.valid4, m[1], (float4 *)xyzw_out, capacity, n_out);
+    if (st != GM_OK) return st;
+    return fetch(ctx, 0, (const float4 *)sl.vnorm4, m[1], (float4 *)nxyzc_out, capacity, n_out);
+}
+
+gm_status gm_get_local_frame(gm_ctx *ctx, const float *nxyzc, uint32_t n, double wf, float eigenvalues[3],
+                             float eigenvectors[9], double scatter6[6])
+{
+    Slot *slp;
+    gm_status st = begin_stage(ctx, slp);
+    if (st != GM_OK) return st;
+    if (n && !nxyzc) return fail(ctx, GM_ERR_INVALID_ARG, "normals pointer is NULL");
+    if (!(wf != 0.0)) return fail(ctx, GM_ERR_INVALID_ARG, "weighting factor must be non-zero");
+    Slot &sl = *slp;
+    st = ensure_capacity(ctx, sl, n, 0, false);
+    if (st != GM_OK) return st;
+    st = reset_counters(ctx, sl);
+    if (st != GM_OK) return st;
+    if (n) GM_HIP(ctx, hipMemcpyAsync(sl.vnorm4, nxyzc, (size_t)n * 16, hipMemcpyHostToDevice, sl.stream));
+    const uint32_t np = launch_scatter_partials(sl.vnorm4, nullptr, n, wf, sl, sl.stream);
+    launch_frame_finalize(np, sl, sl.stream);
+    GM_HIP(ctx, hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(FrameOut), hipMemcpyDeviceToHost, sl.stream));
+    GM_HIP(ctx, hipStreamSynchronize(sl.stream));
+    GM_HIP(ctx, hipGetLastError());
+    if (eigenvalues) for (int k = 0; k < 3; ++k) eigenvalues[k] = sl.h_out->evals[k];
+    if (eigenvectors) for (int k = 0; k < 9; ++k) eigenvectors[k] = sl.h_out->evecs[k];
+    if (scatter6) for (int k = 0; k < 6; ++k) scatter6[k] = sl.h_out->scatter[k];
+    return GM_OK;
+}
+
+gm_status gm_voxel_grid(gm_ctx *ctx, const float *xyz, uint32_t n, double leaf, float *xyzc_out, uint32_t capacity,
+                        uint32_t *n_out, uint32_t *status_flags)
+{
+    Slot *slp;
+    gm_status st = begin_stage(ctx, slp);
+    if (st != GM_OK) return st;
+    if (n && !xyz) return fail(ctx, GM_ERR_INVALID_ARG, "xyz is NULL");
+    if (!(leaf > 0.0) || !std::isfinite(leaf)) return fail(ctx, GM_ERR_INVALID_ARG, "leaf must be finite and > 0");
+    Slot &sl = *slp;
+    st = ensure_capacity(ctx, sl, n, (size_t)n * 16, true);
+    if (st != GM_OK) return st;
+    st = reset_counters(ctx, sl);
+    if (st != GM_OK) return st;
+    float mn = 3e38f, mx = -3e38f;
+    float4 *stage = (float4 *)sl.h_raw;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *p = xyz + 3 * (size_t)i;
+        stage[i] = make_float4(p[0], p[1], p[2], 0.f);
+        for (int k = 0; k < 3; ++k) { mn = fminf(mn, p[k]); mx = fmaxf(mx, p[k]); }
+    }
+    if (n) GM_HIP(ctx, hipMemcpyAsync(sl.valid4, stage, (size_t)n * 16, hipMemcpyHostToDevice, sl.stream));
+    GM_HIP(ctx, hipMemcpyAsync(&sl.ctr->vox_n, &n, 4, hipMemcpyHostToDevice, sl.stream));
+    launch_minmax(sl.valid4, nullptr, n, sl.ctr, sl.stream);
+    launch_voxel_grid(sl, n, (float)leaf, n ? voxel_key_bits(mn, mx, leaf) : 1, sl.stream);
+    uint32_t V = 0, pass = 0;
+    GM_HIP(ctx, hipMemcpyAsync(&V, &sl.ctr->n_voxels, 4, hipMemcpyDeviceToHost, sl.stream));
+    GM_HIP(ctx, hipMemcpyAsync(&pass, &sl.voxp->passthrough, 4, hipMemcpyDeviceToHost, sl.stream));
+    GM_HIP(ctx, hipStreamSynchronize(sl.stream));
+    GM_HIP(ctx, hipGetLastError());
+    if (status_flags) *status_flags = pass ? GM_RES_VOXEL_PASSTHROUGH : 0u;
+    return fetch(ctx, 0, (const float4 *)sl.vox4, V, (float4 *)xyzc_out, capacity, n_out);
+}
+
+gm_status gm_solve_local_frame(const double scatter6[6], float eigenvalues[3], float eigenvectors[9])
+{
+    if (!scatter6 || !eigenvalues || !eigenvectors) return GM_ERR_INVALID_ARG;
+    double w[3], V[9];
+    jacobi_eig3(scatter6, w, V);
+    for (int k = 0; k < 3; ++k) eigenvalues[k] = (float)w[k];
+    for (int k = 0; k < 9; ++k) eigenvectors[k] = (float)V[k];
+    return GM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// gm_internal.hpp -- host-side context and the launch functions each kernel
+// file exports.  Nothing here is visible through the C ABI (include/gm_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/gm_hip.h"
+#include "gm_device.hpp"
+
+namespace gm {
+
+// How x,y,z are pulled out of sensor_msgs/PointCloud2 rows
+// (pcl::fromROSMsg, /root/reference src/geometric_mapping.cpp:55).
+struct RowLayout {
+    const uint8_t *data;
+    uint32_t step, ox, oy, oz;
+    uint32_t mode;  // 0: 16-byte rows x,y,z at 0/4/8 (one dwordx4 load)  1: 4-byte aligned  2: byte loads
+    uint32_t bswap; // PointCloud2.is_bigendian
+};
+
+struct SortScratch {
+    uint32_t *hist;       // [bins * nblocks]
+    uint32_t hist_cap;
+};
+
+// One in-flight frame: its stream, staging and device buffers (grow-only).
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[GM_N_STAGES + 1] = {};
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // around the normals kernel alone
+    uint32_t cap = 0;          // point capacity of the buffers below
+    size_t raw_cap = 0;        // bytes
+    uint8_t *h_raw = nullptr;  // pinned staging for the incoming rows
+    uint8_t *d_raw = nullptr;
+    float4 *crop4 = nullptr;   // cropped cloud: x,y,z, bits(input row)
+    uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
+    float4 *spts4 = nullptr;   // cropped cloud in cell-sorted order: x,y,z, bits(cropped index)
+    uint32_t *skeys = nullptr; // == whichever of keys_a/keys_b holds the sorted keys
+    float4 *normals4 = nullptr;   // per cropped point: nx,ny,nz,curvature (NaN when <3 neighbours)
+    int32_t *counts = nullptr;    // per cropped point neighbour count (GM_CFG_KEEP_COUNTS)
+    float4 *valid4 = nullptr;     // compacted cloud (finite normals)
+    float4 *vnorm4 = nullptr;     // compacted normals
+    uint2 *tiles = nullptr;
+    uint32_t tiles_cap = 0;
+    uint32_t *blk = nullptr;      // per-block counts / offsets for the compactions
+    uint32_t blk_cap = 0;
+    SortScratch sort = {};
+    uint32_t *seg_start = nullptr;
+    float4 *vox4 = nullptr;       // voxel centroids: x,y,z,count
+    int32_t *vox_nn = nullptr;
+    double *partials = nullptr;   // [kScatterBlocks][6]
+    uint8_t *labels = nullptr;
+    DevCounters *ctr = nullptr;
+    VoxelParams *voxp = nullptr;
+    FrameOut *d_out = nullptr;
+    FrameOut *h_out = nullptr;    // pinned
+    // extension scratch
+    float *hyp = nullptr;         // [H][8]
+    int32_t *hyp_counts = nullptr;
+    double *seg_mom = nullptr;
+    // state
+    bool submitted = false, complete = false;
+    uint32_t n_in = 0;
+    gm_frame_result last = {};
+};
+
+}  // namespace gm
+
+struct gm_ctx {
+    gm_config cfg;
+    int device = 0;
+    uint32_t n_slots = 1;
+    gm::Slot *slots = nullptr;
+    double own_lo, own_hi;
+    std::string err;
+};
+
+namespace gm {
+
+constexpr int kScatterBlocks = 1024;
+
+// ---- launchers (each enqueues on `s`, never synchronises) --------------------
+
+// k_crop.hip
+void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const GridParams &g, Slot &sl, hipStream_t s);
+// k_sort.hip : stable LSD radix sort of (key,val) pairs; n is device-resident.
+// Returns 0 if the sorted data ends in (keys_a, vals_a), 1 if in (keys_b, vals_b).
+int launch_radix_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
+                      const uint32_t *n_ptr, uint32_t n_cap, int key_bits, SortScratch &sc, hipStream_t s);
+void launch_exclusive_scan(uint32_t *data, uint32_t count, uint32_t *total_out, uint32_t *total_out2, hipStream_t s);
+uint32_t radix_hist_entries(uint32_t n_cap);
+// k_normals.hip
+void launch_grid_and_normals(const GridParams &g, Slot &sl, uint32_t n_cap, bool keep_counts, hipStream_t s);
+uint32_t max_tiles(uint32_t n_cap, const GridParams &g);
+// k_frame.hip
+void launch_compact_valid(Slot &sl, uint32_t n_cap, float own_lo, float own_hi, hipStream_t s);
+// scatter partials over vnorm4[0..n); returns the number of partial rows written
+uint32_t launch_scatter_partials(const float4 *vnorm4, const uint32_t *n_ptr, uint32_t n_cap, double wf, Slot &sl,
+                                 hipStream_t s);
+void launch_frame_finalize(uint32_t n_partials, Slot &sl, hipStream_t s);
+// k_voxel.hip
+void launch_voxel_grid(Slot &sl, uint32_t n_cap, float leaf, int key_bits, hipStream_t s);
+void launch_minmax(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, DevCounters *ctr, hipStream_t s);
+
+}  // namespace gm

@@ -1,0 +1,126 @@
+// k_crop.hip -- PointCloud2 row ingest fused with the crop box and its
+// order-preserving compaction; also emits the search-grid cell key of every
+// survivor so no later pass has to re-read the cloud for it.
+//
+// Replaces pcl::fromROSMsg (/root/reference src/geometric_mapping.cpp:55) and
+// chopCloud -> pcl::CropBox (/root/reference src/tunnel_processing.cpp:39-49).
+// HBM-bound: reads point_step bytes per input row (twice: count + scatter, the
+// second pass hits the 256 MiB Infinity Cache for frames below ~10 M points),
+// writes 16 + 4 bytes per survivor.
+#include "gm_compact.hpp"
+#include "gm_internal.hpp"
+
+namespace gm {
+
+__device__ __forceinline__ float load_f32_bytes(const uint8_t *p)
+{
+    uint32_t u = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    return __uint_as_float(u);
+}
+
+struct RowReader {
+    RowLayout L;
+    __device__ __forceinline__ void load(uint32_t i, float &x, float &y, float &z) const
+    {
+        const uint8_t *row = L.data + (size_t)i * L.step;
+        if (L.mode == 0) {
+            float4 v = *reinterpret_cast<const float4 *>(row);
+            x = v.x; y = v.y; z = v.z;
+        } else if (L.mode == 1) {
+            x = *reinterpret_cast<const float *>(row + L.ox);
+            y = *reinterpret_cast<const float *>(row + L.oy);
+            z = *reinterpret_cast<const float *>(row + L.oz);
+        } else {
+            x = load_f32_bytes(row + L.ox);
+            y = load_f32_bytes(row + L.oy);
+            z = load_f32_bytes(row + L.oz);
+        }
+        if (L.bswap) {
+            x = __uint_as_float(__builtin_bswap32(__float_as_uint(x)));
+            y = __uint_as_float(__builtin_bswap32(__float_as_uint(y)));
+            z = __uint_as_float(__builtin_bswap32(__float_as_uint(z)));
+        }
+    }
+};
+
+// CropBox::applyFilter: outside iff any coordinate < min or > max (closed box);
+// NaN rows dropped (see gm_hip.h / DESIGN.md for the dense-flag caveat).
+struct CropPred {
+    RowReader rd;
+    float lo, hi;
+    __device__ __forceinline__ bool operator()(uint32_t i) const
+    {
+        float x, y, z;
+        rd.load(i, x, y, z);
+        if (!finite3(x, y, z)) return false;
+        return !(x < lo || y < lo || z < lo || x > hi || y > hi || z > hi);
+    }
+};
+
+struct CropEmit {
+    RowReader rd;
+    GridParams g;
+    float4 *__restrict__ crop4;
+    uint32_t *__restrict__ keys;
+    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst) const
+    {
+        float x, y, z;
+        rd.load(src, x, y, z);
+        crop4[dst] = make_float4(x, y, z, __uint_as_float(src));
+        keys[dst] = cell_key(g, x, y, z);
+    }
+};
+
+__global__ __launch_bounds__(1024) void k_exclusive_scan(uint32_t *__restrict__ data, uint32_t count,
+                                                         uint32_t *__restrict__ total_out,
+                                                         uint32_t *__restrict__ total_out2)
+{
+    __shared__ uint32_t wtot[1024 / kWave];
+    const uint32_t per = (count + 1023u) / 1024u;
+    const uint32_t b = threadIdx.x * per;
+    const uint32_t e = (b + per < count) ? b + per : count;
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; ++i) sum += data[i];
+    uint32_t inc = wave_inclusive_scan(sum);
+    const int w = threadIdx.x / kWave;
+    if (lane_id() == kWave - 1) wtot[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 1024 / kWave; ++k) {
+        uint32_t c = wtot[k];
+        if (k < w) woff += c;
+        total += c;
+    }
+    uint32_t run = woff + inc - sum;
+    for (uint32_t i = b; i < e; ++i) {
+        uint32_t v = data[i];
+        data[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0) {
+        if (total_out) *total_out = total;
+        if (total_out2) *total_out2 = total;
+    }
+}
+
+void launch_exclusive_scan(uint32_t *data, uint32_t count, uint32_t *total_out, uint32_t *total_out2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, data, count, total_out, total_out2);
+}
+
+void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const GridParams &g, Slot &sl, hipStream_t s)
+{
+    const uint32_t nb = compact_blocks(n);
+    if (nb == 0) return;  // counters were zeroed: n_cropped stays 0
+    RowReader rd{rows};
+    CropPred pred{rd, lo, hi};
+    CropEmit emit{rd, g, sl.crop4, sl.keys_a};
+    hipLaunchKernelGGL(k_compact_count<CropPred>, dim3(nb), dim3(kCpThreads), 0, s, pred,
+                       (const uint32_t *)nullptr, n, sl.blk);
+    launch_exclusive_scan(sl.blk, nb, &sl.ctr->n_cropped, nullptr, s);
+    hipLaunchKernelGGL((k_compact_scatter<CropPred, CropEmit>), dim3(nb), dim3(kCpThreads), 0, s, pred, emit,
+                       (const uint32_t *)nullptr, n, (const uint32_t *)sl.blk);
+}
+
+}  // namespace gm

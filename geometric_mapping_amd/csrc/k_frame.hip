@@ -1,0 +1,185 @@
+// k_frame.hip -- NaN-normal compaction, the curvature-weighted normal scatter
+// matrix and its 3x3 eigen-decomposition (the "centre axis" fit).
+//
+// Replaces
+//   removeNaNNormalsFromPointCloud + ExtractIndices
+//       (/root/reference src/tunnel_processing.cpp:74-85)
+//   getLocalFrame (/root/reference src/tunnel_processing.cpp:92-148):
+//       w_i = exp((c_i + .001/wf)^2) evaluated in double, stored to float (:106),
+//       M = (W N)^T (W N) = sum_i w_i^2 n_i n_i^T (:119-124), SelfAdjointEigenSolver (:129).
+// The reference materialises W as a dense n x n matrix (4 n^2 bytes); here M is
+// six fp64 running sums per lane over one streaming read of 16 B per point --
+// the HBM-streaming kernel of the path.  fp64 accumulation makes M independent
+// of the reduction order to ~1e-16, so partials from any number of blocks (or
+// GPUs) merge bit-stably.
+#include "gm_compact.hpp"
+#include "gm_internal.hpp"
+
+namespace gm {
+
+// ---- compaction of points with a finite normal ----------------------------------
+struct ValidPred {
+    const float4 *__restrict__ normals4;
+    const float4 *__restrict__ crop4;
+    float own_lo, own_hi;  // slab ownership along x (multi-GPU sharding); +-inf otherwise
+    __device__ __forceinline__ bool operator()(uint32_t i) const
+    {
+        const float4 nn = normals4[i];
+        if (!finite3(nn.x, nn.y, nn.z)) return false;
+        const float x = crop4[i].x;
+        return x >= own_lo && x < own_hi;
+    }
+};
+
+struct ValidEmit {
+    const float4 *__restrict__ normals4;
+    const float4 *__restrict__ crop4;
+    float4 *__restrict__ valid4;
+    float4 *__restrict__ vnorm4;
+    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst) const
+    {
+        valid4[dst] = crop4[src];
+        vnorm4[dst] = normals4[src];
+    }
+};
+
+// min/max of x,y,z over pts[0..n) (getMinMax3D of pcl::VoxelGrid) -> ordered uints
+__global__ __launch_bounds__(256) void k_minmax(const float4 *__restrict__ pts, const uint32_t *__restrict__ n_ptr,
+                                                uint32_t n_host, DevCounters *__restrict__ ctr)
+{
+    __shared__ float red[6][256 / kWave];
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = pts[i];
+        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+    const int w = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float a = wave_min(mn[k]), b = wave_max(mx[k]);
+        if (lane_id() == 0) { red[k][w] = a; red[3 + k][w] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        float v = red[k][0];
+        for (int j = 1; j < 256 / kWave; ++j) v = (k < 3) ? fminf(v, red[k][j]) : fmaxf(v, red[k][j]);
+        if (blockIdx.x * blockDim.x < n) {
+            if (k < 3) atomicMin(&ctr->mm[k], float_to_ordered(v));
+            else atomicMax(&ctr->mm[k], float_to_ordered(v));
+        }
+    }
+}
+
+__global__ void k_init_minmax(DevCounters *ctr)
+{
+    if (threadIdx.x < 3) ctr->mm[threadIdx.x] = 0xFFFFFFFFu;
+    else if (threadIdx.x < 6) ctr->mm[threadIdx.x] = 0u;
+}
+
+void launch_minmax(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, DevCounters *ctr, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(64), 0, s, ctr);
+    if (n_cap == 0) return;
+    uint32_t nb = (n_cap + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(256), 0, s, pts, n_ptr, n_cap, ctr);
+}
+
+void launch_compact_valid(Slot &sl, uint32_t n_cap, float own_lo, float own_hi, hipStream_t s)
+{
+    const uint32_t nb = compact_blocks(n_cap);
+    if (nb == 0) return;
+    ValidPred pred{sl.normals4, sl.crop4, own_lo, own_hi};
+    ValidEmit emit{sl.normals4, sl.crop4, sl.valid4, sl.vnorm4};
+    hipLaunchKernelGGL(k_compact_count<ValidPred>, dim3(nb), dim3(kCpThreads), 0, s, pred,
+                       (const uint32_t *)&sl.ctr->n_cropped, 0u, sl.blk);
+    launch_exclusive_scan(sl.blk, nb, &sl.ctr->n_valid, &sl.ctr->vox_n, s);
+    hipLaunchKernelGGL((k_compact_scatter<ValidPred, ValidEmit>), dim3(nb), dim3(kCpThreads), 0, s, pred, emit,
+                       (const uint32_t *)&sl.ctr->n_cropped, 0u, (const uint32_t *)sl.blk);
+}
+
+// ---- scatter matrix: streaming pass ---------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter_partials(const float4 *__restrict__ vnorm4,
+                                                          const uint32_t *__restrict__ n_ptr, uint32_t n_host,
+                                                          double k_wf /* .001 / weightingFactor */,
+                                                          double *__restrict__ partials)
+{
+    __shared__ double red[256 / kWave][6];
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    double m[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 v = vnorm4[i];  // one coalesced 16 B load per lane: nx,ny,nz,curvature
+        // src/tunnel_processing.cpp:106: float + double -> double, pow(.,2), exp, store to float
+        const double t = (double)v.w + k_wf;
+        const float wgt = (float)exp(t * t);
+        // :119 weights*normals: one fp32 product per component (zeros add exactly)
+        const double a = (double)(wgt * v.x), b = (double)(wgt * v.y), c = (double)(wgt * v.z);
+        // :124 exact fp64 products of those fp32 values
+        m[0] += a * a; m[1] += a * b; m[2] += a * c; m[3] += b * b; m[4] += b * c; m[5] += c * c;
+    }
+    const int w = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double r = wave_sum(m[k]);
+        if (lane_id() == 0) red[w][k] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double r = 0;
+#pragma unroll
+        for (int j = 0; j < 256 / kWave; ++j) r += red[j][threadIdx.x];
+        partials[blockIdx.x * 6 + threadIdx.x] = r;
+    }
+}
+
+// ---- fixed-order reduction of the block partials + 3x3 eigen (one block) ---------
+__global__ __launch_bounds__(256) void k_frame_finalize(const double *__restrict__ partials, uint32_t nblocks,
+                                                        const DevCounters *__restrict__ ctr,
+                                                        const VoxelParams *__restrict__ voxp,
+                                                        FrameOut *__restrict__ out)
+{
+    __shared__ double red[256][6];
+    double m[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t b = threadIdx.x; b < nblocks; b += 256)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) m[k] += partials[b * 6 + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[threadIdx.x][k] = m[k];
+    __syncthreads();
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) red[threadIdx.x][k] += red[threadIdx.x + stride][k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double M[6], w[3], V[9];
+        for (int k = 0; k < 6; ++k) { M[k] = red[0][k]; out->scatter[k] = M[k]; }
+        jacobi_eig3(M, w, V);
+        for (int k = 0; k < 3; ++k) out->evals[k] = (float)w[k];
+        for (int k = 0; k < 9; ++k) out->evecs[k] = (float)V[k];
+        if (ctr) out->ctr = *ctr;
+        if (voxp) out->vox = *voxp;
+    }
+}
+
+uint32_t launch_scatter_partials(const float4 *vnorm4, const uint32_t *n_ptr, uint32_t n_cap, double wf, Slot &sl,
+                                 hipStream_t s)
+{
+    uint32_t nb = (n_cap + 255) / 256;
+    if (nb > (uint32_t)kScatterBlocks) nb = kScatterBlocks;
+    if (nb == 0) nb = 1;
+    hipLaunchKernelGGL(k_scatter_partials, dim3(nb), dim3(256), 0, s, vnorm4, n_ptr, n_cap, .001 / wf, sl.partials);
+    return nb;
+}
+
+void launch_frame_finalize(uint32_t n_partials, Slot &sl, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_frame_finalize, dim3(1), dim3(256), 0, s, (const double *)sl.partials, n_partials,
+                       (const DevCounters *)sl.ctr, (const VoxelParams *)sl.voxp, sl.d_out);
+}
+
+}  // namespace gm

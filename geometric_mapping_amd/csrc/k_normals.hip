@@ -1,0 +1,283 @@
+// k_normals.hip -- fixed-radius neighbourhood covariance -> surface normal +
+// curvature for every cropped point.  THE dominant kernel of the path.
+//
+// Replaces pcl::NormalEstimation::compute with a radius search
+// (/root/reference src/tunnel_processing.cpp:58-70; PCL semantics restated in
+// oracle/gm_oracle.c): neighbour set { j : fl32((dx*dx+dy*dy)+dz*dz) < fl32(r*r) }
+// including the point itself, biased covariance, smallest eigenpair,
+// curvature = |lambda0 / trace|, normal flipped towards the origin, NaN when
+// fewer than 3 neighbours.
+//
+// MI355X design (not a kd-tree walk):
+//  * points are binned into a uniform grid (cell edge >= r) by a stable radix
+//    sort of cell keys, x fastest, so the 3x3x3 neighbourhood of a run of cells
+//    in one x-row is 9 CONTIGUOUS ranges of the sorted array;
+//  * a work item ("tile") is <= 64 consecutive sorted points of one x-row: one
+//    query per lane, the tile's candidates are streamed through a 1 KiB
+//    wave-private LDS window (coalesced 16 B/lane loads in, broadcast
+//    ds_read_b128 out), so no block barrier exists in the hot loop;
+//  * each lane keeps 10 fp32 accumulators of offsets FROM ITS OWN QUERY POINT
+//    (|offset| < r: no cancellation), folded into fp64 once per 64 candidates;
+//  * the 3x3 solve runs in fp64 (MI355X fp64 vector rate is half the fp32 rate;
+//    ~250 instructions against ~15 000 in the neighbour loop);
+//  * tiles are handed out by a device-side work queue (one atomic per tile) to
+//    a persistent grid sized to the chip, which also balances the very uneven
+//    candidate counts.
+// Bound: fp32 VALU issue (~21 ops per query-candidate pair), not HBM: every
+// candidate byte is read once per tile and reused by 64 lanes.
+#include "gm_internal.hpp"
+
+namespace gm {
+
+constexpr int kNrThreads = 256;
+constexpr int kNrWaves = kNrThreads / kWave;
+
+// ---- gather the cropped cloud into cell-sorted order ---------------------------
+__global__ __launch_bounds__(256) void k_gather_sorted(const float4 *__restrict__ crop4,
+                                                       const uint32_t *__restrict__ perm,
+                                                       const uint32_t *__restrict__ n_ptr,
+                                                       float4 *__restrict__ spts4)
+{
+    const uint32_t n = *n_ptr;
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+        const uint32_t i = perm[s];
+        float4 p = crop4[i];
+        p.w = __uint_as_float(i);  // cropped index rides in the pad lane
+        spts4[s] = p;
+    }
+}
+
+// ---- tiles: <=64 consecutive sorted points of one x-row -------------------------
+__global__ __launch_bounds__(256) void k_build_tiles(const uint32_t *__restrict__ skeys,
+                                                     DevCounters *__restrict__ ctr, uint32_t nx,
+                                                     uint2 *__restrict__ tiles, uint32_t tiles_cap)
+{
+    const uint32_t n = ctr->n_cropped;
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+        const uint32_t row = skeys[s] / nx;
+        if (s != 0 && skeys[s - 1] / nx == row) continue;  // not the first point of its row
+        // one past the last point of this row
+        const uint32_t e = lower_bound_u32(skeys, n, (row + 1u) * nx);
+        const uint32_t cnt = (e - s + kWave - 1) / kWave;
+        uint32_t t = atomicAdd(&ctr->n_tiles, cnt);
+        for (uint32_t b = s; b < e; b += kWave, ++t)
+            if (t < tiles_cap) tiles[t] = make_uint2(b, (e - b < (uint32_t)kWave) ? e - b : (uint32_t)kWave);
+    }
+}
+
+// ---- smallest eigenpair of a symmetric PSD 3x3, fp64 ----------------------------
+// c = {xx,xy,xz,yy,yz,zz}.  Root of the characteristic cubic: closed form with
+// fp32 trigonometry as the starting point, two Newton steps in fp64; eigenvector
+// = largest cross product of two rows of (C - lambda I) (pcl::eigen33's choice).
+// Returns false when every cross product is exactly zero (PCL divides 0/0 there
+// and the point is then removed as a NaN normal).
+__device__ __forceinline__ bool smallest_eigpair(const double c[6], double &lam, double v[3])
+{
+    const double tr = c[0] + c[3] + c[5];
+    const double m = tr * (1.0 / 3.0);
+    const double k0 = c[0] - m, k3 = c[3] - m, k5 = c[5] - m;
+    const double p = (k0 * k0 + k3 * k3 + k5 * k5 + 2.0 * (c[1] * c[1] + c[2] * c[2] + c[4] * c[4])) * (1.0 / 6.0);
+    double l0 = m;
+    if (p > 0.0) {
+        const double q = 0.5 * (k0 * (k3 * k5 - c[4] * c[4]) - c[1] * (c[1] * k5 - c[4] * c[2]) +
+                                c[2] * (c[1] * c[4] - k3 * c[2]));
+        const double sp = sqrt(p);
+        double disc = p * p * p - q * q;
+        if (disc < 0.0) disc = 0.0;
+        const float phi = atan2f((float)sqrt(disc), (float)q) * (1.0f / 3.0f);
+        float sn, cs;
+        __sincosf(phi, &sn, &cs);
+        // smallest root of the three (phi in [0, pi/3])
+        l0 = m - sp * ((double)cs + 1.7320508075688772 * (double)sn);
+        // Newton on f(l) = det(C - l I)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const double a = c[0] - l0, b = c[3] - l0, d = c[5] - l0;
+            const double f = a * (b * d - c[4] * c[4]) - c[1] * (c[1] * d - c[4] * c[2]) + c[2] * (c[1] * c[4] - b * c[2]);
+            const double fp = -(b * d + a * d + a * b - c[1] * c[1] - c[2] * c[2] - c[4] * c[4]);
+            if (fabs(fp) > 1e-300) {
+                const double step = f / fp;
+                // never step past the neighbouring root: |step| is bounded by the gap scale
+                if (fabs(step) < sp) l0 -= step;
+            }
+        }
+    }
+    if (l0 < 0.0) l0 = 0.0;  // PSD matrix: a negative root is rounding (pcl::computeRoots does the same)
+    lam = l0;
+    const double r0[3] = {c[0] - l0, c[1], c[2]};
+    const double r1[3] = {c[1], c[3] - l0, c[4]};
+    const double r2[3] = {c[2], c[4], c[5] - l0};
+    double v1[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+    double v2[3] = {r0[1] * r2[2] - r0[2] * r2[1], r0[2] * r2[0] - r0[0] * r2[2], r0[0] * r2[1] - r0[1] * r2[0]};
+    double v3[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+    const double n1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
+    const double n2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
+    const double n3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
+    double nn;
+    if (n1 >= n2 && n1 >= n3) { v[0] = v1[0]; v[1] = v1[1]; v[2] = v1[2]; nn = n1; }
+    else if (n2 >= n1 && n2 >= n3) { v[0] = v2[0]; v[1] = v2[1]; v[2] = v2[2]; nn = n2; }
+    else { v[0] = v3[0]; v[1] = v3[1]; v[2] = v3[2]; nn = n3; }
+    if (!(nn > 0.0)) return false;
+    const double inv = 1.0 / sqrt(nn);
+    v[0] *= inv; v[1] *= inv; v[2] *= inv;
+    return true;
+}
+
+// ---- the neighbourhood kernel ----------------------------------------------------
+__global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict__ spts4,
+                                                        const uint32_t *__restrict__ skeys,
+                                                        const uint2 *__restrict__ tiles,
+                                                        DevCounters *__restrict__ ctr, GridParams g,
+                                                        uint32_t tiles_cap, float4 *__restrict__ normals4,
+                                                        int32_t *__restrict__ counts)
+{
+    __shared__ float4 win[kNrWaves][kWave];  // one 1 KiB candidate window per wave
+    const int lane = lane_id();
+    const int w = threadIdx.x / kWave;
+    const uint32_t n = ctr->n_cropped;
+    uint32_t ntiles = ctr->n_tiles;
+    if (ntiles > tiles_cap) ntiles = tiles_cap;
+
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&ctr->tile_next, 1u);
+        t = __shfl(t, 0, kWave);
+        if (t >= ntiles) break;  // every wave reaches this: the queue only grows
+        const uint2 tile = tiles[t];
+        const uint32_t qs = tile.x, qn = tile.y;
+
+        // tile geometry: one x-row, cells [cxa, cxb]
+        const uint32_t ka = skeys[qs], kb = skeys[qs + qn - 1];
+        const uint32_t row = ka / (uint32_t)g.nx;
+        const int cxa = (int)(ka - row * (uint32_t)g.nx), cxb = (int)(kb - row * (uint32_t)g.nx);
+        const int cy = (int)(row % (uint32_t)g.ny), cz = (int)(row / (uint32_t)g.ny);
+        const int x0 = cxa > 0 ? cxa - 1 : 0, x1 = cxb < g.nx - 1 ? cxb + 1 : g.nx - 1;
+
+        // 9 candidate ranges (one per neighbouring x-row); lanes 0..8 find begin,
+        // lanes 16..24 find end, by binary search in the sorted keys
+        uint32_t bound = 0;
+        {
+            const int r = lane & 15;
+            if (r < 9 && (lane < 9 || (lane >= 16 && lane < 25))) {
+                const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
+                if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                    const uint32_t rb = (uint32_t)((zz * g.ny + yy) * g.nx);
+                    bound = (lane < 16) ? lower_bound_u32(skeys, n, rb + (uint32_t)x0)
+                                        : lower_bound_u32(skeys, n, rb + (uint32_t)x1 + 1u);
+                }
+            }
+        }
+        uint32_t rbeg[9], rpre[10];
+        rpre[0] = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const uint32_t b = __shfl(bound, r, kWave), e = __shfl(bound, 16 + r, kWave);
+            rbeg[r] = b;
+            rpre[r + 1] = rpre[r] + (e - b);  // invalid rows: b == e == 0
+        }
+        const uint32_t total = rpre[9];
+
+        // this lane's query
+        const bool active = (uint32_t)lane < qn;
+        const float4 q = spts4[qs + (active ? lane : 0)];
+
+        int cnt = 0;
+        double Sx = 0, Sy = 0, Sz = 0, Sxx = 0, Sxy = 0, Sxz = 0, Syy = 0, Syz = 0, Szz = 0;
+
+        for (uint32_t v0 = 0; v0 < total; v0 += kWave) {
+            // map the flattened candidate index to its range
+            const uint32_t vv = v0 + lane;
+            float4 cp = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);  // never within r of anything
+            if (vv < total) {
+                uint32_t src = rbeg[0] + vv;
+#pragma unroll
+                for (int r = 1; r < 9; ++r)
+                    if (vv >= rpre[r]) src = rbeg[r] + (vv - rpre[r]);
+                cp = spts4[src];
+            }
+            wave_lds_fence();  // previous window fully consumed
+            win[w][lane] = cp;
+            wave_lds_fence();
+            const int m = (total - v0 < (uint32_t)kWave) ? (int)(total - v0) : kWave;
+            const int m4 = (m + 3) & ~3;  // padding slots hold far-away points
+            float sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+#pragma unroll 4
+            for (int j = 0; j < m4; ++j) {
+                const float4 c = win[w][j];  // same address in every lane: LDS broadcast
+                const float dx = c.x - q.x, dy = c.y - q.y, dz = c.z - q.z;
+                // FLANN L2_Simple: every product and sum rounded, in this order
+                const float xx = __fmul_rn(dx, dx), yy = __fmul_rn(dy, dy), zz = __fmul_rn(dz, dz);
+                const float d2 = __fadd_rn(__fadd_rn(xx, yy), zz);
+                if (d2 < g.r2) {  // RadiusResultSet::addPoint: strict
+                    ++cnt;
+                    sx += dx; sy += dy; sz += dz;
+                    sxx += xx; syy += yy; szz += zz;
+                    sxy = fmaf(dx, dy, sxy); sxz = fmaf(dx, dz, sxz); syz = fmaf(dy, dz, syz);
+                }
+            }
+            Sx += sx; Sy += sy; Sz += sz;
+            Sxx += sxx; Sxy += sxy; Sxz += sxz; Syy += syy; Syz += syz; Szz += szz;
+        }
+
+        if (active) {
+            const uint32_t dst = __float_as_uint(q.w);
+            float4 out = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+            if (cnt >= 3) {  // NormalEstimation::computePointNormal
+                const double inv_n = 1.0 / (double)cnt;
+                const double mx = Sx * inv_n, my = Sy * inv_n, mz = Sz * inv_n;
+                double c[6];
+                c[0] = Sxx * inv_n - mx * mx; c[1] = Sxy * inv_n - mx * my; c[2] = Sxz * inv_n - mx * mz;
+                c[3] = Syy * inv_n - my * my; c[4] = Syz * inv_n - my * mz; c[5] = Szz * inv_n - mz * mz;
+                double lam, nv[3];
+                if (smallest_eigpair(c, lam, nv)) {
+                    const double trc = c[0] + c[3] + c[5];
+                    const double curv = (trc != 0.0) ? fabs(lam / trc) : 0.0;
+                    // flipNormalTowardsViewpoint(p, 0,0,0)
+                    const double ct = -((double)q.x * nv[0] + (double)q.y * nv[1] + (double)q.z * nv[2]);
+                    const double sgn = (ct < 0.0) ? -1.0 : 1.0;
+                    out = make_float4((float)(sgn * nv[0]), (float)(sgn * nv[1]), (float)(sgn * nv[2]), (float)curv);
+                }
+            }
+            normals4[dst] = out;
+            if (counts) counts[dst] = cnt;
+        }
+    }
+}
+
+uint32_t max_tiles(uint32_t n_cap, const GridParams &g)
+{
+    // every x-row adds at most one partially filled tile
+    const uint64_t rows = (uint64_t)g.ny * (uint64_t)g.nz;
+    const uint64_t extra = rows < n_cap ? rows : n_cap;
+    return (uint32_t)(n_cap / kWave + extra + 1);
+}
+
+void launch_grid_and_normals(const GridParams &g, Slot &sl, uint32_t n_cap, bool keep_counts, hipStream_t s)
+{
+    if (n_cap == 0) return;
+    // bits needed by the largest cell key
+    const uint64_t ncell = (uint64_t)g.nx * g.ny * g.nz;
+    int bits = 1;
+    while ((1ull << bits) < ncell) ++bits;
+    const int where = launch_radix_sort(sl.keys_a, sl.vals_a, sl.keys_b, sl.vals_b, &sl.ctr->n_cropped, n_cap, bits,
+                                        sl.sort, s);
+    uint32_t *skeys = where ? sl.keys_b : sl.keys_a;
+    uint32_t *perm = where ? sl.vals_b : sl.vals_a;
+    sl.skeys = skeys;
+    const uint32_t gb = (n_cap + 255) / 256 < 2048 ? (n_cap + 255) / 256 : 2048;
+    hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(256), 0, s, (const float4 *)sl.crop4, (const uint32_t *)perm,
+                       (const uint32_t *)&sl.ctr->n_cropped, sl.spts4);
+    hipLaunchKernelGGL(k_build_tiles, dim3(gb), dim3(256), 0, s, (const uint32_t *)skeys, sl.ctr, (uint32_t)g.nx,
+                       sl.tiles, sl.tiles_cap);
+    // persistent grid: 8 blocks of 4 waves per CU fill every SIMD's 8 wave slots
+    const uint32_t mt = max_tiles(n_cap, g);
+    uint32_t nb = (mt + kNrWaves - 1) / kNrWaves;
+    if (nb > 2048) nb = 2048;
+    hipEventRecord(sl.ev_k0, s);
+    hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), 0, s, (const float4 *)sl.spts4, (const uint32_t *)skeys,
+                       (const uint2 *)sl.tiles, sl.ctr, g, sl.tiles_cap, sl.normals4,
+                       keep_counts ? sl.counts : (int32_t *)nullptr);
+    hipEventRecord(sl.ev_k1, s);
+}
+
+}  // namespace gm

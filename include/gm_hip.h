@@ -1,0 +1,232 @@
+/*
+ * gm_hip.h -- C ABI of libgm_hip.so: the MI355X (gfx950) implementation of the
+ * geometric_mapping per-frame point-cloud path.
+ *
+ * The reference exposes this path as plain C++ free functions linked into one
+ * ROS executable (there is no plugin / FFI layer to bind to):
+ *   /root/reference include/geometric_mapping/tunnel_processing.hpp:38-54,77-82
+ *   called only from cloud_cb, /root/reference src/geometric_mapping.cpp:48-125.
+ * This header is the boundary a catkin host links instead; every entry point
+ * cites the reference interface it replaces.  No PCL / Eigen / ROS / torch
+ * types cross it: plain pointers, sizes and POD structs only.  Nothing throws.
+ *
+ * Threading: a gm_ctx is NOT thread-safe (the reference's callback never
+ * re-enters either: ros::spin(), src/geometric_mapping.cpp:169).  Use one
+ * context per calling thread.  All device work of a context runs on HIP
+ * streams it owns (one per slot).
+ *
+ * There is no CPU fallback behind this ABI: if no gfx950 device is usable,
+ * gm_create fails with GM_ERR_DEVICE.
+ */
+#ifndef GM_HIP_H
+#define GM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GM_ABI_VERSION 1u
+
+typedef struct gm_ctx gm_ctx; /* opaque */
+
+typedef enum gm_status {
+    GM_OK = 0,
+    GM_ERR_INVALID_ARG = 1,
+    GM_ERR_TOO_FEW_POINTS = 2, /* reserved: stages accept empty clouds like the reference does */
+    GM_ERR_DEVICE = 3,         /* a HIP call failed; gm_last_error() has the hipError string */
+    GM_ERR_OOM = 4,
+    GM_ERR_CAPACITY = 5,       /* caller buffer too small; *n_out holds the needed count */
+    GM_ERR_NOT_READY = 6,      /* slot has no submitted / completed frame */
+    GM_ERR_UNSUPPORTED = 7
+} gm_status;
+
+/* gm_config.flags */
+#define GM_CFG_VOXEL_GRID      (1u << 0) /* run VoxelGrid every frame, as the reference does
+                                            (src/geometric_mapping.cpp:70-75 is not gated) */
+#define GM_CFG_NEAREST         (1u << 1) /* also 1-NN of every voxel centroid
+                                            (src/tunnel_processing.cpp:237-239; only /surfaceNormals needs it) */
+#define GM_CFG_RANSAC_PLANE    (1u << 2) /* extension, no reference counterpart */
+#define GM_CFG_RANSAC_CYLINDER (1u << 3) /* extension, no reference counterpart */
+#define GM_CFG_STAGE_TIMING    (1u << 4) /* bracket stages with hipEvents -> gm_frame_result.stage_ms */
+#define GM_CFG_KEEP_COUNTS     (1u << 5) /* keep per-point neighbour counts (tests) */
+#define GM_CFG_DEFAULT         (GM_CFG_VOXEL_GRID)
+
+/* The four numeric parameters are the reference's, with its types:
+ * include/geometric_mapping/paramHandler.hpp:26-29 (all double). */
+typedef struct gm_config {
+    uint32_t struct_size;        /* = sizeof(gm_config) */
+    uint32_t flags;              /* GM_CFG_* */
+    double   boxFilterBound;     /* launch/mapping.launch:7  */
+    double   voxelGridLeafSize;  /* launch/mapping.launch:8  */
+    double   neighborRadius;     /* launch/mapping.launch:9  */
+    double   weightingFactor;    /* launch/mapping.launch:10 */
+    int32_t  device;             /* HIP device ordinal */
+    uint32_t n_slots;            /* frames in flight (>=1); 2 overlaps H2D of frame i+1 with compute of i */
+    uint32_t max_points;         /* capacity hint; buffers grow on demand */
+    uint32_t ransac_hypotheses;  /* H per model per frame (extension) */
+    double   ransac_threshold;   /* tau, metres (extension) */
+    uint64_t ransac_seed;        /* extension */
+} gm_config;
+
+/* gm_cloud.flags */
+#define GM_CLOUD_DEVICE    (1u << 0) /* data is a device pointer valid on the context's device */
+#define GM_CLOUD_BIGENDIAN (1u << 1) /* sensor_msgs/PointCloud2.is_bigendian */
+
+/* One sensor_msgs/PointCloud2 worth of rows: what pcl::fromROSMsg reads at
+ * src/geometric_mapping.cpp:55.  x,y,z are float32 at byte offsets off_* of
+ * each point_step-byte row. */
+typedef struct gm_cloud {
+    const void *data;
+    uint32_t n_points;
+    uint32_t point_step;
+    uint32_t off_x, off_y, off_z;
+    uint32_t flags;
+} gm_cloud;
+
+enum { GM_STAGE_UPLOAD = 0, GM_STAGE_CROP, GM_STAGE_GRID, GM_STAGE_NORMALS, GM_STAGE_COMPACT,
+       GM_STAGE_FRAME, GM_STAGE_VOXEL, GM_STAGE_RANSAC, GM_STAGE_TOTAL, GM_N_STAGES };
+
+/* gm_frame_result.status_flags */
+#define GM_RES_VOXEL_PASSTHROUGH (1u << 0) /* PCL "leaf size too small" guard: voxel output = input */
+
+typedef struct gm_frame_result {
+    uint32_t n_in;         /* points received */
+    uint32_t n_cropped;    /* after chopCloud                          (src/geometric_mapping.cpp:57) */
+    uint32_t n_valid;      /* after NaN-normal removal inside getNormals (:63)                       */
+    uint32_t n_voxels;     /* VoxelGrid output size                    (src/tunnel_processing.cpp:220) */
+    float    eigenvalues[3];   /* ascending, = *eigenVals              (src/tunnel_processing.cpp:132) */
+    float    eigenvectors[9];  /* column-major like Eigen::Matrix3f    (src/tunnel_processing.cpp:136) */
+    float    center_axis[3];   /* eigenvectors column 0                (src/geometric_mapping.cpp:92)  */
+    uint32_t status_flags;
+    double   scatter[6];       /* M = sum w^2 n n^T: xx,xy,xz,yy,yz,zz in fp64 (multi-GPU merge unit) */
+    /* extensions (valid only with the GM_CFG_RANSAC_* flags) */
+    uint32_t plane_inliers, cylinder_inliers;
+    float    plane[4];         /* a,b,c,d  (unit normal)                */
+    float    cylinder[7];      /* point on axis, unit axis direction, radius */
+    double   plane_refit[4];   /* least-squares refit over the plane segment */
+    double   cylinder_axis_refit[3]; /* min-eigenvector of sum nn^T over the cylinder segment */
+    float    stage_ms[GM_N_STAGES];  /* device time per stage when GM_CFG_STAGE_TIMING; else 0 */
+    float    normals_kernel_ms;      /* the neighbourhood-normals kernel alone (hipEvent bracketed) */
+} gm_frame_result;
+
+/* ---- lifetime ------------------------------------------------------------ */
+
+/* Replaces the start-up half of main(): src/geometric_mapping.cpp:128-161
+ * (parameters are read once; there is no dynamic reconfigure).  Picks the
+ * device, creates one stream + pinned staging + device buffers per slot. */
+gm_status gm_create(const gm_config *cfg, gm_ctx **out);
+void gm_destroy(gm_ctx *ctx);
+
+/* Defaults = the launch file's values (launch/mapping.launch:7-10). */
+void gm_default_config(gm_config *cfg);
+
+uint32_t gm_abi_version(void);
+const char *gm_status_string(gm_status s);
+/* Message of the last failure on this context ("" if none).  ctx may be NULL
+ * for a failure inside gm_create. */
+const char *gm_last_error(const gm_ctx *ctx);
+
+/* ---- the per-frame callback ------------------------------------------------ */
+
+/* Replaces the processing half of cloud_cb, src/geometric_mapping.cpp:55-92:
+ * fromROSMsg -> chopCloud -> getNormals -> VoxelGrid (inside rvizNormals) ->
+ * getLocalFrame -> centerAxis.  Blocking; uses slot 0. */
+gm_status gm_process_frame(gm_ctx *ctx, const gm_cloud *cloud, gm_frame_result *res);
+
+/* Same work split for streaming (BASELINE config 5): submit returns once the
+ * host buffer has been staged and all device work is enqueued on the slot's
+ * stream; wait blocks until that frame's result is on the host.  The host
+ * buffer may be reused as soon as submit returns. */
+gm_status gm_submit_frame(gm_ctx *ctx, uint32_t slot, const gm_cloud *cloud);
+gm_status gm_wait_frame(gm_ctx *ctx, uint32_t slot, gm_frame_result *res);
+
+/* Bulky per-frame outputs of a completed slot, fetched only when a display
+ * flag needs them (src/geometric_mapping.cpp:100-117).  `capacity` counts
+ * points; *n_out receives the available count (also on GM_ERR_CAPACITY).
+ *   cropped xyz : /choppedCloud = cloudChopped AFTER the in-place NaN compaction
+ *                 (src/tunnel_processing.cpp:81-85), rows of 4 floats x,y,z,pad
+ *                 = pcl::PointXYZ; pad holds the point's row index in the input
+ *                 cloud as int32 bits.
+ *   normals     : rows nx,ny,nz,curvature (the meaningful fields of pcl::Normal)
+ *   voxels      : VoxelGrid centroids in ascending voxel-key order, rows x,y,z,count
+ *   nearest     : for each voxel centroid, index (into the cropped cloud) of its
+ *                 nearest point (needs GM_CFG_NEAREST) */
+gm_status gm_get_cropped_xyz(gm_ctx *ctx, uint32_t slot, float *xyzw, uint32_t capacity, uint32_t *n_out);
+gm_status gm_get_normals(gm_ctx *ctx, uint32_t slot, float *nxyzc, uint32_t capacity, uint32_t *n_out);
+gm_status gm_get_voxel_centroids(gm_ctx *ctx, uint32_t slot, float *xyzc, uint32_t capacity, uint32_t *n_out);
+gm_status gm_get_voxel_nearest(gm_ctx *ctx, uint32_t slot, int32_t *idx, uint32_t capacity, uint32_t *n_out);
+/* per-point neighbour counts of the cropped cloud, pre-compaction order (GM_CFG_KEEP_COUNTS) */
+gm_status gm_get_neighbor_counts(gm_ctx *ctx, uint32_t slot, int32_t *counts, uint32_t capacity, uint32_t *n_out);
+/* extension: per-point segment label of the valid cloud: 0 none, 1 plane, 2 cylinder */
+gm_status gm_get_labels(gm_ctx *ctx, uint32_t slot, uint8_t *labels, uint32_t capacity, uint32_t *n_out);
+
+/* ---- the reference's stage functions, one call each ------------------------ */
+/* Host buffers in, host buffers out (blocking, slot 0).  These exist so the
+ * four signatures of tunnel_processing.hpp can be re-implemented one-to-one. */
+
+/* chopCloud(bound, cloud): tunnel_processing.hpp:38, src/tunnel_processing.cpp:39-49.
+ * Order-preserving.  out rows x,y,z,pad(=input row index). */
+gm_status gm_chop_cloud(gm_ctx *ctx, const gm_cloud *cloud, double bound,
+                        float *xyzw_out, uint32_t capacity, uint32_t *n_out);
+
+/* getNormals(radius, cloud&, kdtree&): tunnel_processing.hpp:41-45,
+ * src/tunnel_processing.cpp:52-89.  xyz rows of 3 floats in; compacted cloud
+ * (rows x,y,z,pad(=input row)) and normals (nx,ny,nz,curvature) out, same
+ * length and order, NaN-normal rows removed. */
+gm_status gm_get_normals_stage(gm_ctx *ctx, const float *xyz, uint32_t n, double radius,
+                               float *xyzw_out, float *nxyzc_out, uint32_t capacity, uint32_t *n_out);
+
+/* getLocalFrame(n, wf, normals, vals*&, vecs*&): tunnel_processing.hpp:48-54,
+ * src/tunnel_processing.cpp:92-148.  eigenvectors column-major. */
+gm_status gm_get_local_frame(gm_ctx *ctx, const float *nxyzc, uint32_t n, double weighting_factor,
+                             float eigenvalues[3], float eigenvectors[9], double scatter6[6]);
+
+/* The pcl::VoxelGrid half of rvizNormals: tunnel_processing.hpp:77-82,
+ * src/tunnel_processing.cpp:214-220.  out rows x,y,z,count. */
+gm_status gm_voxel_grid(gm_ctx *ctx, const float *xyz, uint32_t n, double leaf,
+                        float *xyzc_out, uint32_t capacity, uint32_t *n_out, uint32_t *status_flags);
+
+/* kdtree->nearestKSearch(q, 1): src/tunnel_processing.cpp:237-239. */
+gm_status gm_nearest(gm_ctx *ctx, const float *xyz, uint32_t n, const float *queries, uint32_t nq,
+                     int32_t *idx_out);
+
+/* ---- multi-GPU merge unit (SURVEY.md par. 8e) ------------------------------- */
+
+/* Eigen-solve a merged scatter matrix (sum over shards of gm_frame_result.scatter).
+ * Pure host arithmetic on 6 doubles; same Jacobi as the device epilogue. */
+gm_status gm_solve_local_frame(const double scatter6[6], float eigenvalues[3], float eigenvectors[9]);
+
+/* Restrict which cropped points act as QUERY points: only points whose x lies in
+ * [own_lo, own_hi) get a normal (the rest are halo: neighbours only, dropped
+ * from the outputs).  Defaults to (-inf, +inf).  Used by slab sharding. */
+gm_status gm_set_owned_range(gm_ctx *ctx, double own_lo, double own_hi);
+
+/* ---- extensions without a reference counterpart (SURVEY.md par. 8a-ext) ----- */
+
+/* Score caller-supplied hypotheses against a host cloud (xyz rows of 3 floats).
+ * plane rows a,b,c,d: inlier iff |a x + b y + c z + d| < tau.
+ * cylinder rows px,py,pz,dx,dy,dz,r: inlier iff (r-tau)^2 < dist_axis^2 < (r+tau)^2. */
+gm_status gm_score_planes(gm_ctx *ctx, const float *xyz, uint32_t n, const float *hyp4, uint32_t H,
+                          double tau, int32_t *counts);
+gm_status gm_score_cylinders(gm_ctx *ctx, const float *xyz, uint32_t n, const float *hyp7, uint32_t H,
+                             double tau, int32_t *counts);
+/* Seeded minimal-sample hypotheses generated on the device. */
+gm_status gm_plane_hypotheses(gm_ctx *ctx, const float *xyz, uint32_t n, uint64_t seed, uint32_t H, float *hyp4);
+gm_status gm_cylinder_hypotheses(gm_ctx *ctx, const float *xyz, const float *nxyzc, uint32_t n,
+                                 uint64_t seed, uint32_t H, float *hyp7);
+/* Per-segment moments: mom16 = count, sum p (3), sum pp^T (6), sum nn^T (6). */
+gm_status gm_segment_moments(gm_ctx *ctx, const float *xyz, const float *nxyzc, const uint8_t *labels,
+                             uint32_t n, uint32_t label, double mom16[16]);
+
+/* Compressed map record of a completed slot (build-defined format):
+ * header + primitive records + voxel centroids.  Returns bytes needed in
+ * *n_bytes (also on GM_ERR_CAPACITY). */
+gm_status gm_get_compressed_map(gm_ctx *ctx, uint32_t slot, void *buf, size_t capacity, size_t *n_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GM_HIP_H */

@@ -282,6 +282,12 @@ static void normal_from_neighbours_f64(const float *xyz, const float *q, const n
     C[0] = s[0] - s[6] * s[6]; C[1] = s[1] - s[6] * s[7]; C[2] = s[2] - s[6] * s[8];
     C[4] = s[3] - s[7] * s[7]; C[5] = s[4] - s[7] * s[8]; C[8] = s[5] - s[8] * s[8];
     C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
+    if (C[0] == 0.0 && C[1] == 0.0 && C[2] == 0.0 && C[4] == 0.0 && C[5] == 0.0 && C[8] == 0.0) {
+        /* all neighbours coincide: pcl::eigen33 normalises a zero cross product
+         * (0/0) -> NaN normal, and the point is then removed as NaN */
+        out[0] = out[1] = out[2] = out[3] = NAN;
+        return;
+    }
     double w[3], V[9];
     gmo_eig3(C, w, V);
     double nx = V[0], ny = V[1], nz = V[2];

@@ -1,0 +1,303 @@
+"""GPU parity tests: the HIP path (through the C ABI, ctypes) against the CPU
+oracle on the same seeded inputs.  Run on the MI355X box with `-m gpu`.
+
+Tolerances (stated once, used below):
+  * crop, NaN removal, neighbour counts, voxel keys/counts: bit-exact (integer / index work);
+  * voxel centroids: 1 float ulp-ish (2e-6 absolute on |x|<=5) vs the f64 oracle;
+  * per-point normal direction: 1e-5 rad; per-point curvature: 1e-4 relative
+    (fp32 neighbour accumulation; the reference's own fp32 formula is ~3e-3 off the
+    f64 value, SURVEY.md par. 7);
+  * frame outputs (north_star's 1e-5): centre axis 1e-5 rad, lambda1/lambda2 1e-5 relative,
+    lambda0 1e-5 of lambda2 (it is a near-null eigenvalue: absolute, not relative).
+"""
+import numpy as np
+import pytest
+
+from geometric_mapping_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+B, R, LEAF, WF = 5.0, 0.5, 0.5, 0.2
+
+
+def ang(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    s = np.linalg.norm(np.cross(a, b), axis=-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+    return np.arcsin(np.clip(s, 0, 1))
+
+
+@pytest.fixture(scope="module")
+def ctx(gm):
+    from geometric_mapping_amd import _lib
+    c = gm.GeometricMapping(boxFilterBound=B, voxelGridLeafSize=LEAF, neighborRadius=R, weightingFactor=WF,
+                            flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_KEEP_COUNTS | _lib.GM_CFG_STAGE_TIMING)
+    yield c
+    c.close()
+
+
+# ------------------------------------------------------------------ stages
+
+def test_chop_cloud_bit_exact(ctx, oc):
+    xyz = synth.tunnel_frame(50000, seed=3, outlier_frac=0.02)
+    xyz[17] = [np.nan, 0, 0]
+    xyz[18] = [0, np.inf, 0]
+    xyz[19] = [5.0, -5.0, 5.0]
+    xyz[20] = [np.nextafter(np.float32(5), np.float32(9)), 0, 0]
+    out, rows = ctx.chopCloud(B, xyz)
+    keep = oc.crop_box(xyz, B)
+    assert np.array_equal(rows, keep)
+    assert np.array_equal(out, xyz[keep])
+    assert 19 in rows and 20 not in rows and 17 not in rows and 18 not in rows
+
+
+def test_chop_cloud_empty_and_all_outside(ctx):
+    out, rows = ctx.chopCloud(B, np.zeros((0, 3), np.float32))
+    assert out.shape == (0, 3)
+    out, rows = ctx.chopCloud(B, np.full((1000, 3), 9.0, np.float32))
+    assert out.shape == (0, 3)
+
+
+@pytest.mark.parametrize("step,offs", [(12, (0, 4, 8)), (16, (0, 4, 8)), (32, (4, 8, 12)), (22, (0, 4, 8)), (22, (1, 9, 17))])
+def test_chop_cloud_pointcloud2_layouts(ctx, oc, step, offs):
+    xyz = synth.tunnel_frame(20000, seed=5)
+    rows = synth.to_pointcloud2(xyz, point_step=step, offsets=offs, fill=0xAB)
+    out, kept = ctx.chopCloud(B, ctx.cloud_from_rows(rows, len(xyz), step, offs))
+    keep = oc.crop_box(xyz, B)
+    assert np.array_equal(kept, keep) and np.array_equal(out, xyz[keep])
+
+
+def test_chop_cloud_bigendian(ctx, oc):
+    xyz = synth.tunnel_frame(5000, seed=6)
+    be = xyz.astype(">f4").view(np.uint8).reshape(-1)
+    out, kept = ctx.chopCloud(B, ctx.cloud_from_rows(be, len(xyz), 12, (0, 4, 8), bigendian=True))
+    keep = oc.crop_box(xyz, B)
+    assert np.array_equal(kept, keep) and np.array_equal(out, xyz[keep])
+
+
+@pytest.mark.parametrize("n,seed,axis,radius", [(20000, 0, (1, 0, 0), 0.5), (30000, 5, (1, 0.2, -0.1), 0.4),
+                                                (8000, 2, (0, 0, 1), 0.7)])
+def test_get_normals_vs_oracle(ctx, oc, n, seed, axis, radius):
+    xyz = synth.tunnel_frame(n, seed=seed, axis=axis, outlier_frac=0.01)
+    xyz = xyz[oc.crop_box(xyz, B)]
+    nrm, cloud, rows = ctx.getNormals(radius, xyz)
+    o_n, o_cnt = oc.normals(xyz, radius, oc.F64)
+    keep = oc.finite_normals(o_n)
+    assert np.array_equal(rows, keep)                       # same NaN-normal removal
+    assert np.array_equal(cloud, xyz[keep])
+    cnt = ctx.neighbor_counts()                              # kept by GM_CFG_KEEP_COUNTS: pre-compaction order
+    assert np.array_equal(cnt, o_cnt)                        # identical neighbour SETS sizes, every point
+    o = o_n[keep]
+    a = ang(nrm[:, :3], o[:, :3])
+    # eigen-gap weighted: the direction is only defined to ~eps/gap; on this data the gap is healthy
+    assert np.quantile(a, 0.999) < 1e-5 and a.max() < 1e-4
+    assert (np.sign((nrm[:, :3] * o[:, :3]).sum(axis=1)) > 0).mean() > 0.999   # same flip
+    rel = np.abs(nrm[:, 3] - o[:, 3]) / np.maximum(o[:, 3], 1e-12)
+    assert np.quantile(rel, 0.999) < 1e-4
+
+
+def test_get_normals_isolated_and_degenerate(ctx, oc):
+    xyz = synth.cylinder_frame(3000, seed=2)
+    lonely = np.array([[0, 0, 0], [0.0, 0.0, 0.3], [4.0, 4.0, 4.0], [4.0, 4.0, 4.2]], dtype=np.float32)
+    same = np.tile(np.array([[3.0, -3.0, 3.0]], np.float32), (5, 1))      # zero covariance -> NaN (PCL divides 0/0)
+    cloud = np.vstack([xyz, lonely, same]).astype(np.float32)
+    nrm, out, rows = ctx.getNormals(0.35, cloud)
+    o_n, _ = oc.normals(cloud, 0.35, oc.F64)
+    keep = oc.finite_normals(o_n)
+    assert np.array_equal(rows, keep)
+    assert rows.max() < len(xyz)
+
+
+def test_get_normals_radius_strict(ctx):
+    pts = np.array([[0, 0, 0], [0.5, 0, 0], [0, 0.5, 0], [0, 0, 0.5]], dtype=np.float32)
+    ctx.getNormals(0.5, pts)
+    assert ctx.neighbor_counts().tolist() == [1, 1, 1, 1]
+    ctx.getNormals(0.5000001, pts)
+    assert ctx.neighbor_counts().tolist() == [4, 2, 2, 2]
+
+
+def test_get_normals_plane_known_answer(ctx):
+    nvec = np.array([1.0, 2.0, 2.0]) / 3.0
+    xyz = synth.plane_patch(4000, seed=1, normal=nvec, offset=1.5, half=1.5)
+    nrm, cloud, rows = ctx.getNormals(0.4, xyz)
+    assert len(nrm) == len(xyz)
+    assert ang(nrm[:, :3], nvec).max() < 2e-6
+    assert nrm[:, 3].max() < 1e-7
+    assert ((-xyz.astype(np.float64) * nrm[:, :3]).sum(axis=1) >= 0).all()
+
+
+def test_voxel_grid_vs_oracle(ctx, oc):
+    xyz = synth.tunnel_frame(40000, seed=4)
+    xyz = xyz[oc.crop_box(xyz, B)]
+    for leaf in (0.5, 0.1, 0.27):
+        cen, cnt, pt = ctx.voxelGrid(leaf, xyz)
+        o_c, o_k, o_n, o_pt = oc.voxel_grid(xyz, leaf, oc.F64)
+        assert pt == o_pt and len(cen) == len(o_c)
+        assert np.array_equal(cnt, o_n)                      # same voxels, same order, same membership
+        assert np.abs(cen - o_c).max() < 2e-6
+
+
+def test_voxel_grid_known_answers(ctx):
+    pts = np.array([[0.1, 0.1, 0.1], [0.2, 0.2, 0.2], [0.3, 0.3, 0.3]], dtype=np.float32)
+    cen, cnt, pt = ctx.voxelGrid(0.5, pts)
+    assert cnt.tolist() == [3] and np.allclose(cen[0], 0.2, atol=1e-7)
+    pts = np.array([[-0.1, 0, 0], [0.1, 0, 0], [-0.4, 0, 0]], dtype=np.float32)
+    cen, cnt, pt = ctx.voxelGrid(0.5, pts)
+    assert cnt.tolist() == [2, 1] and np.allclose(cen[0], [-0.25, 0, 0], atol=1e-7)
+    cen, cnt, pt = ctx.voxelGrid(0.5, np.zeros((0, 3), np.float32))
+    assert len(cen) == 0
+
+
+def test_voxel_grid_leaf_too_small_passthrough(ctx, oc):
+    pts = np.array([[-5, -5, -5], [5, 5, 5], [0, 0, 0], [1, 2, 3]], dtype=np.float32)
+    cen, cnt, pt = ctx.voxelGrid(0.005, pts)
+    assert pt and np.array_equal(cen, pts)
+
+
+def test_local_frame_vs_oracle(ctx, oc):
+    xyz = synth.cylinder_frame(30000, seed=7, axis=(1, 0.2, -0.1))
+    nrm, _ = oc.normals(xyz, R, oc.F64)
+    nrm = nrm[oc.finite_normals(nrm)]
+    ev, V, M = ctx.getLocalFrame(len(nrm), WF, nrm)
+    o_ev, o_V, o_M = oc.local_frame(nrm, WF, oc.F64)
+    assert np.abs(M - o_M).max() / np.abs(o_M).max() < 5e-7   # fp32 store of w (reference semantics) vs double w
+    assert ang(V[:, 0], o_V[:, 0]) < 1e-5
+    assert abs(ev[1] - o_ev[1]) / o_ev[1] < 1e-5 and abs(ev[2] - o_ev[2]) / o_ev[2] < 1e-5
+    assert abs(ev[0] - o_ev[0]) < 1e-5 * o_ev[2]
+    assert np.allclose(V.T @ V, np.eye(3), atol=1e-6)
+    # f32-faithful restatement of the reference's own arithmetic lands in the same place
+    f_ev, f_V, _ = oc.local_frame(nrm, WF, oc.F32_FAITHFUL)
+    assert ang(V[:, 0], f_V[:, 0]) < 2e-5
+
+
+def test_local_frame_known_answers(ctx):
+    n = 1000
+    nrm = np.tile(np.array([[0, 0, 1, 0]], dtype=np.float32), (n, 1))
+    ev, V, M = ctx.getLocalFrame(n, WF, nrm)
+    w = np.float32(np.exp((0.001 / WF) ** 2))
+    assert abs(ev[2] - n * float(w) ** 2) < 1e-4 and abs(ev[0]) < 1e-6 and abs(ev[1]) < 1e-6
+    ev, V, M = ctx.getLocalFrame(0, WF, np.zeros((0, 4), np.float32))
+    assert np.all(ev == 0) and np.all(M == 0)
+    # cloudSize smaller than the cloud: only the first cloudSize rows count (tunnel_processing.cpp:104)
+    nrm2 = np.vstack([nrm, np.tile(np.array([[1, 0, 0, 0]], np.float32), (10, 1))])
+    ev2, _, M2 = ctx.getLocalFrame(n, WF, nrm2)
+    assert abs(M2[0, 0]) < 1e-12
+
+
+# ------------------------------------------------------------------ whole frame
+
+@pytest.mark.parametrize("n,seed,axis,kw", [
+    (50000, 0, (1, 0, 0), {}),                                           # BASELINE configs[0] shape
+    (50000, 1, (1, 0.2, -0.1), dict(outlier_frac=0.01)),
+    (60000, 2, (1, 0, 0), dict(floor_z=-1.2, outlier_frac=0.01)),        # plane + cylinder + outliers
+])
+def test_process_frame_vs_oracle(ctx, oc, n, seed, axis, kw):
+    xyz = synth.tunnel_frame(n, seed=seed, axis=axis, **kw)
+    res = ctx.process_frame(xyz)
+    o = oc.process_frame(xyz, B, R, LEAF, WF, oc.F64)
+    for k in ("n_in", "n_cropped", "n_valid", "n_voxels"):
+        assert res[k] == o[k], k
+    cloud, rows = ctx.cropped_cloud()
+    assert np.array_equal(cloud, o["xyz"])                   # /choppedCloud: same points, same order
+    assert np.array_equal(xyz[rows], cloud)
+    nrm = ctx.normals()
+    a = ang(nrm[:, :3], o["normals"][:, :3])
+    assert np.quantile(a, 0.999) < 1e-5
+    rel = np.abs(nrm[:, 3] - o["normals"][:, 3]) / np.maximum(o["normals"][:, 3], 1e-12)
+    assert np.quantile(rel, 0.999) < 1e-4
+    cen, cnt = ctx.voxel_centroids()
+    assert np.abs(cen - o["voxels"]).max() < 2e-6
+    # north_star bar: 1e-5
+    assert ang(res["eigenvectors"][:, 0], o["evecs"][:, 0]) < 1e-5
+    assert ang(res["center_axis"], o["evecs"][:, 0]) < 1e-5
+    l, lo = res["eigenvalues"].astype(np.float64), o["evals"].astype(np.float64)
+    assert abs(l[1] - lo[1]) / lo[1] < 1e-5 and abs(l[2] - lo[2]) / lo[2] < 1e-5
+    assert abs(l[0] - lo[0]) < 1e-5 * lo[2]
+    assert np.abs(res["scatter"] - o["M"]).max() / np.abs(o["M"]).max() < 1e-5
+    # the f32-faithful restatement of the reference agrees to the same bar on the well-posed outputs
+    f = oc.process_frame(xyz, B, R, LEAF, WF, oc.F32_FAITHFUL, want_outputs=False)
+    assert ang(res["center_axis"], f["evecs"][:, 0]) < 3e-5
+    # (its lambdas carry the reference's sequential-fp32 summation error, ~sqrt(n)*eps)
+    assert abs(l[2] - f["evals"][2]) / lo[2] < 1e-4
+
+
+def test_process_frame_is_deterministic(ctx):
+    xyz = synth.tunnel_frame(40000, seed=9, outlier_frac=0.01)
+    a = ctx.process_frame(xyz)
+    na = ctx.normals()
+    b = ctx.process_frame(xyz)
+    nb = ctx.normals()
+    assert np.array_equal(na, nb)                             # bitwise: stable sort + fixed-order sums
+    assert np.array_equal(a["scatter6"], b["scatter6"])
+    assert np.array_equal(a["eigenvectors"], b["eigenvectors"])
+
+
+def test_process_frame_edge_cases(ctx):
+    r = ctx.process_frame(np.zeros((0, 3), np.float32))
+    assert r["n_in"] == 0 and r["n_cropped"] == 0 and r["n_valid"] == 0 and r["n_voxels"] == 0
+    assert np.all(r["eigenvalues"] == 0)
+    r = ctx.process_frame(np.full((500, 3), 7.0, np.float32))          # everything outside the box
+    assert r["n_cropped"] == 0 and r["n_valid"] == 0
+    r = ctx.process_frame(np.array([[0, 0, 1], [0, 1, 0]], np.float32))  # fewer than 3 points: all NaN normals
+    assert r["n_cropped"] == 2 and r["n_valid"] == 0
+    # ragged size right after a big frame (grow-only buffers, stale data must not leak)
+    ctx.process_frame(synth.tunnel_frame(30000, seed=1))
+    r = ctx.process_frame(synth.tunnel_frame(777, seed=2))
+    assert r["n_in"] == 777 and 0 < r["n_cropped"] <= 777
+
+
+def test_process_frame_device_resident_rows(ctx, oc):
+    torch = pytest.importorskip("torch")
+    xyz = synth.tunnel_frame(30000, seed=3)
+    rows = np.zeros((len(xyz), 4), np.float32)
+    rows[:, :3] = xyz
+    t = torch.from_numpy(rows).cuda()
+    torch.cuda.synchronize()
+    res = ctx.process_frame(ctx.cloud_from_device(t.data_ptr(), len(xyz), 16))
+    ref = ctx.process_frame(xyz)
+    assert res["n_valid"] == ref["n_valid"]
+    assert np.array_equal(res["scatter6"], ref["scatter6"])
+
+
+def test_streaming_slots(gm, oc):
+    frames = [synth.tunnel_frame(20000, seed=s) for s in range(6)]
+    with gm.GeometricMapping(n_slots=2) as c:
+        single = [c.process_frame(f)["scatter6"] for f in frames]
+        out = [None] * len(frames)
+        c.submit_frame(0, frames[0])
+        for i in range(1, len(frames)):
+            c.submit_frame(i % 2, frames[i])
+            out[i - 1] = c.wait_frame((i - 1) % 2)["scatter6"]
+        out[-1] = c.wait_frame((len(frames) - 1) % 2)["scatter6"]
+    for a, b in zip(single, out):
+        assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ full-size, size-independent properties
+
+def test_full_size_properties_1m(gm):
+    n = 1_000_000
+    r = synth.fixed_k_radius(n)
+    xyz = synth.tunnel_frame(n, seed=0)
+    with gm.GeometricMapping(neighborRadius=r) as c:
+        res = c.process_frame(xyz)
+        cloud, rows = c.cropped_cloud()
+        nrm = c.normals()
+        cen, cnt = c.voxel_centroids()
+    inside = np.all(np.abs(xyz) <= 5.0, axis=1)
+    assert res["n_cropped"] == int(inside.sum())
+    assert np.all(np.diff(rows) > 0) and np.array_equal(xyz[rows], cloud)     # order-preserving
+    assert np.isfinite(nrm).all()
+    assert np.abs(np.linalg.norm(nrm[:, :3].astype(np.float64), axis=1) - 1).max() < 1e-6
+    assert ((-cloud.astype(np.float64) * nrm[:, :3]).sum(axis=1) >= 0).all()  # flipped to the sensor
+    assert cnt.sum() == res["n_valid"] and res["n_voxels"] == len(cen)
+    # scatter matrix: symmetric PSD, trace = sum w^2 >= n
+    M = res["scatter"]
+    assert np.trace(M) >= res["n_valid"] and np.trace(M) < 1.3 * res["n_valid"]
+    assert res["eigenvalues"][0] >= -1e-3 and np.all(np.diff(res["eigenvalues"]) >= 0)
+    assert ang(res["center_axis"], [1, 0, 0]) < 2e-3                           # analytic truth: tunnel along x
+    # linearity: M(frame) == M(first half of normals) + M(second half)
+    h = len(nrm) // 2
+    with gm.GeometricMapping() as c2:
+        _, _, Ma = c2.getLocalFrame(h, WF, nrm[:h])
+        _, _, Mb = c2.getLocalFrame(len(nrm) - h, WF, nrm[h:])
+    assert np.abs((Ma + Mb) - M).max() / np.abs(M).max() < 1e-12
