@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- points/sec of the full per-frame path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (ingest+crop -> cell sort -> radius normals ->
+NaN compaction -> voxel grid -> scatter matrix + 3x3 eigen [-> RANSAC ext]) over one
+synthetic 1M-point tunnel frame whose PointCloud2 rows are already resident in HBM.
+Workload = BASELINE.json configs[1] ("1M-pt synthetic tunnel frame, single MI355X"),
+fixed-k neighbour radius r = 0.5*sqrt(50000/N) (SURVEY.md par. 8d), launch-file values
+for everything else.
+
+N > 1 (one process per GPU, RCCL via torch.distributed):
+  --mode frames (default): every rank runs its own stream of 1M-pt frames (frames are
+      independent: BASELINE config 5); the only collective is one all-gather of the
+      fitted records at the end of the timed region.  scaling = weak.
+  --mode slab: ONE frame cut into x-slabs with a radius halo; per step each rank
+      processes its slab, all-gathers a 10-double record (scatter partials + counts)
+      over RCCL and solves the merged 3x3.  scaling = strong.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy peak 6290
+HBM_MEASURED_GBS = 6290.0
+ALGO_BYTES_PER_POINT = 40.0    # SURVEY.md par. 8d: 12 B/pt in + 28 B per cropped point out
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=1_000_000)
+    ap.add_argument("--radius", type=float, default=None, help="default: fixed-k 0.5*sqrt(50000/points)")
+    ap.add_argument("--mode", choices=("frames", "slab"), default="frames")
+    ap.add_argument("--slots", type=int, default=2, help="frames in flight per GPU (HIP streams)")
+    ap.add_argument("--ransac", type=int, default=1, help="1: include the cylinder RANSAC model (extension) when built")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(points, radius, threads):
+    """The oracle (f32-faithful restatement of the reference's PCL/Eigen path), timed on
+    this box's host cores on ONE frame of the same workload.  Baseline only."""
+    from geometric_mapping_amd import synth
+    from oracle import oracle_c as oc
+    oc.build()
+    xyz = synth.tunnel_frame(points, seed=0)
+    ncores = threads or (os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    oc.process_frame(xyz, 5.0, radius, 0.5, 0.2, oc.F32_FAITHFUL, nthreads=ncores, want_outputs=False)
+    dt_all = time.perf_counter() - t0
+    # single thread = how the reference actually executes (ros::spin, non-OMP NormalEstimation);
+    # bounded: one fifth of the frame at the same density (same radius => same k)
+    sub = xyz[: points // 5]
+    r_sub = radius  # k scales with density; keep the work per point comparable by keeping k: r*sqrt(5)
+    t0 = time.perf_counter()
+    oc.process_frame(sub, 5.0, r_sub * np.sqrt(5.0), 0.5, 0.2, oc.F32_FAITHFUL, nthreads=1, want_outputs=False)
+    dt_one = time.perf_counter() - t0
+    return {"value": points / dt_all, "unit": "points/s", "cores": int(ncores), "kind": "port",
+            "sample": f"1 frame of the same workload ({points} pts, r={radius:.4f}), oracle f32_faithful, OpenMP over query points",
+            "single_thread_value": (points // 5) / dt_one,
+            "single_thread_sample": f"{points // 5} pts at matched k (r*sqrt(5)), 1 thread"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    import torch  # before libgm_hip: one HIP runtime per process (geometric_mapping_amd/_lib.py)
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback to time)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import geometric_mapping_amd as g
+    from geometric_mapping_amd import _lib, sharding, synth
+
+    n = args.points
+    radius = args.radius if args.radius else synth.fixed_k_radius(n)
+    bound, leaf, wf = 5.0, 0.5, 0.2
+    flags = _lib.GM_CFG_DEFAULT
+    ransac_on = False
+    if args.ransac:
+        probe = g.load_library()
+        # the extension is part of the step only once its kernels exist in the library
+        ransac_on = bool(getattr(probe, "gm_ext_available", None) and probe.gm_ext_available())
+        if ransac_on:
+            flags |= _lib.GM_CFG_RANSAC_CYLINDER
+
+    def rows16(xyz):
+        a = np.zeros((len(xyz), 4), dtype=np.float32)
+        a[:, :3] = xyz
+        return a
+
+    n_slots = max(1, args.slots)
+    mode = args.mode if world > 1 else "frames"
+    if mode == "frames":
+        n_frames = 4
+        frames_host = [synth.tunnel_frame(n, seed=1000 * rank + s) for s in range(n_frames)]
+        dev = [torch.from_numpy(rows16(f)).cuda() for f in frames_host]
+        pts_per_step_rank = n
+        own = None
+    else:
+        full = synth.tunnel_frame(n, seed=0)
+        edges = sharding.slab_edges(full, world, bound)
+        rows = sharding.cut_slabs(full, edges, halo=radius * 1.01)[rank]
+        dev = [torch.from_numpy(rows16(full[rows])).cuda()]
+        pts_per_step_rank = None  # the frame is shared: n points per step for the whole job
+        own = (edges[rank], edges[rank + 1])
+        n_slots = 1
+    torch.cuda.synchronize()
+
+    ctx = g.GeometricMapping(boxFilterBound=bound, voxelGridLeafSize=leaf, neighborRadius=radius, weightingFactor=wf,
+                             device=local_rank, flags=flags, n_slots=n_slots, max_points=max(len(d) for d in dev))
+    if own is not None:
+        ctx.set_owned_range(*own)
+    clouds = [ctx.cloud_from_device(d.data_ptr(), d.shape[0], 16) for d in dev]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    rec_dev = torch.zeros(sharding.RECORD_LEN, dtype=torch.float64, device="cuda")
+    gathered = torch.zeros(world * sharding.RECORD_LEN, dtype=torch.float64, device="cuda")
+
+    def slab_step(i):
+        res = ctx.process_frame(clouds[0])
+        rec_dev.copy_(torch.from_numpy(sharding.pack_record(res)))
+        dist.all_gather_into_tensor(gathered, rec_dev)
+        sc, _ = sharding.unpack_records(gathered.cpu().numpy())
+        ev, V = g.solve_local_frame(sharding.merge_scatter(sc))
+        return res, ev, V
+
+    results = []
+
+    def run(steps, collect):
+        if mode == "slab":
+            for i in range(steps):
+                r = slab_step(i)
+                if collect:
+                    results.append(r[0])
+            return
+        # frames: keep n_slots frames in flight on their own HIP streams
+        inflight = []
+        for i in range(steps):
+            slot = i % n_slots
+            if len(inflight) == n_slots:
+                r = ctx.wait_frame(inflight.pop(0))
+                if collect:
+                    results.append(r)
+            ctx.submit_frame(slot, clouds[i % len(clouds)])
+            inflight.append(slot)
+        while inflight:
+            r = ctx.wait_frame(inflight.pop(0))
+            if collect:
+                results.append(r)
+
+    run(args.warmup, False)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    if world > 1 and mode == "frames":
+        # fitted records of every rank's last frame to every rank (the node publishes them all)
+        rec_dev.copy_(torch.from_numpy(sharding.pack_record(results[-1])))
+        dist.all_gather_into_tensor(gathered, rec_dev)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    total_points = (n * args.steps * world) if mode == "frames" else (n * args.steps)
+    value = total_points / dt
+
+    # dominant kernel: the neighbourhood-normals kernel, HIP-event bracketed on the stream
+    # it runs on, inside the timed region (gm_frame_result.normals_kernel_ms)
+    k_ms = float(np.mean([r["normals_kernel_ms"] for r in results])) if results else 0.0
+    n_crop = float(np.mean([r["n_cropped"] for r in results])) if results else 0.0
+    algo_bytes = 28.0 * n_crop                      # SURVEY par. 8d: normals = 12 N' read + 16 N' written
+    achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "r01_normals_pmc.json")
+    if os.path.exists(prof) and mode == "frames":
+        try:
+            with open(prof) as f:
+                pj = json.load(f)
+            if pj.get("points") == n and abs(pj.get("radius", 0) - radius) < 1e-9:
+                traffic = pj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "points/sec full segment+fit, 1M-pt synthetic tunnel frame",
+            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if mode == "frames" else "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n}-pt synthetic tunnel frame (R=2 m, L=12 m, sigma=0.01), rows resident in HBM",
+                       "neighborRadius": radius, "k_regime": "fixed-k (~256 neighbours)", "boxFilterBound": bound,
+                       "voxelGridLeafSize": leaf, "weightingFactor": wf, "mode": mode, "frames_in_flight": n_slots,
+                       "ransac_model": "cylinder (extension)" if ransac_on else "none (reference-faithful path)",
+                       "parallelism": f"{mode}x{world}"},
+            "roofline": {"kernel": "k_normals", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "VALU-bound neighbour loop (k~256): HBM fraction is reported as the contract asks; "
+                                 "see DESIGN.md for the VALU roofline of this kernel"},
+            "whole_path_hbm": {"algorithmic_bytes_per_point": ALGO_BYTES_PER_POINT,
+                               "achieved_GBs": value * ALGO_BYTES_PER_POINT / 1e9,
+                               "frac_of_spec": value * ALGO_BYTES_PER_POINT / 1e9 / HBM_PEAK_GBS},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(n, radius, args.cpu_threads)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

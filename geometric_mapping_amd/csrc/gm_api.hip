@@ -113,8 +113,7 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
     GM_HIP(ctx, dmalloc(sl.valid4, cap)); GM_HIP(ctx, dmalloc(sl.vnorm4, cap));
     GM_HIP(ctx, dmalloc(sl.seg_start, cap)); GM_HIP(ctx, dmalloc(sl.vox4, cap));
     GM_HIP(ctx, dmalloc(sl.vox_nn, cap)); GM_HIP(ctx, dmalloc(sl.labels, cap));
-    sl.tiles_cap = cap / kWave + 1024u * 1024u + 2u;  // n/64 + at most 1024*1024 x-rows
-    if (sl.tiles_cap > cap + cap / kWave + 2u) sl.tiles_cap = cap + cap / kWave + 2u;
+    sl.tiles_cap = cap + cap / kWave + 2u;  // every tile holds >= 1 point; n/64 full ones at most
     GM_HIP(ctx, dmalloc(sl.tiles, sl.tiles_cap));
     sl.blk_cap = compact_blocks(cap) + 1;
     GM_HIP(ctx, dmalloc(sl.blk, sl.blk_cap));

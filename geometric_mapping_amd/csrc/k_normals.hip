@@ -29,7 +29,26 @@
 
 namespace gm {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// products / sums that must NOT be contracted into an fma (the neighbour predicate)
+__device__ __forceinline__ v2f pk_mul_rn(v2f a, v2f b)
+{
+    v2f r;
+    r.x = __fmul_rn(a.x, b.x);
+    r.y = __fmul_rn(a.y, b.y);
+    return r;
+}
+__device__ __forceinline__ v2f pk_add_rn(v2f a, v2f b)
+{
+    v2f r;
+    r.x = __fadd_rn(a.x, b.x);
+    r.y = __fadd_rn(a.y, b.y);
+    return r;
+}
+
 constexpr int kNrThreads = 256;
+constexpr int kTileSpan = 2;  // cells of one x-row a tile may span
 constexpr int kNrWaves = kNrThreads / kWave;
 
 // ---- gather the cropped cloud into cell-sorted order ---------------------------
@@ -47,17 +66,28 @@ __global__ __launch_bounds__(256) void k_gather_sorted(const float4 *__restrict_
     }
 }
 
-// ---- tiles: <=64 consecutive sorted points of one x-row -------------------------
+// ---- tiles: <=64 consecutive sorted points of one group of `span` cells of one x-row ----
+// Bounding the x-extent of a tile bounds its candidate count (sparse rows would
+// otherwise produce tiles spanning tens of cells: a 20x outlier that the whole
+// grid then waits for).
 __global__ __launch_bounds__(256) void k_build_tiles(const uint32_t *__restrict__ skeys,
-                                                     DevCounters *__restrict__ ctr, uint32_t nx,
+                                                     DevCounters *__restrict__ ctr, uint32_t nx, uint32_t span,
                                                      uint2 *__restrict__ tiles, uint32_t tiles_cap)
 {
     const uint32_t n = ctr->n_cropped;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
-        const uint32_t row = skeys[s] / nx;
-        if (s != 0 && skeys[s - 1] / nx == row) continue;  // not the first point of its row
-        // one past the last point of this row
-        const uint32_t e = lower_bound_u32(skeys, n, (row + 1u) * nx);
+        const uint32_t key = skeys[s];
+        const uint32_t row = key / nx;
+        const uint32_t gx = (key - row * nx) / span;
+        if (s != 0) {
+            const uint32_t pk = skeys[s - 1];
+            const uint32_t prow = pk / nx;
+            if (prow == row && (pk - prow * nx) / span == gx) continue;  // not the first point of its group
+        }
+        // one past the last point of this group
+        uint32_t kend = row * nx + (gx + 1u) * span;
+        if (kend > (row + 1u) * nx) kend = (row + 1u) * nx;
+        const uint32_t e = lower_bound_u32(skeys, n, kend);
         const uint32_t cnt = (e - s + kWave - 1) / kWave;
         uint32_t t = atomicAdd(&ctr->n_tiles, cnt);
         for (uint32_t b = s; b < e; b += kWave, ++t)
@@ -131,7 +161,9 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
                                                         uint32_t tiles_cap, float4 *__restrict__ normals4,
                                                         int32_t *__restrict__ counts)
 {
-    __shared__ float4 win[kNrWaves][kWave];  // one 1 KiB candidate window per wave
+    // candidate window, one per wave, SoA so that one broadcast ds_read_b128 feeds
+    // the x (or y, z) of FOUR candidates to every lane
+    __shared__ __attribute__((aligned(16))) float win[kNrWaves][3][kWave];
     const int lane = lane_id();
     const int w = threadIdx.x / kWave;
     const uint32_t n = ctr->n_cropped;
@@ -181,8 +213,10 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
         const bool active = (uint32_t)lane < qn;
         const float4 q = spts4[qs + (active ? lane : 0)];
 
-        int cnt = 0;
-        double Sx = 0, Sy = 0, Sz = 0, Sxx = 0, Sxy = 0, Sxz = 0, Syy = 0, Syz = 0, Szz = 0;
+        double Sn = 0, Sx = 0, Sy = 0, Sz = 0, Sxx = 0, Sxy = 0, Sxz = 0, Syy = 0, Syz = 0, Szz = 0;
+        const v2f qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
+        const v2f r2v = {g.r2, g.r2};
+        const float *wx = &win[w][0][0], *wy = &win[w][1][0], *wz = &win[w][2][0];
 
         for (uint32_t v0 = 0; v0 < total; v0 += kWave) {
             // map the flattened candidate index to its range
@@ -196,28 +230,48 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
                 cp = spts4[src];
             }
             wave_lds_fence();  // previous window fully consumed
-            win[w][lane] = cp;
+            win[w][0][lane] = cp.x; win[w][1][lane] = cp.y; win[w][2][lane] = cp.z;
             wave_lds_fence();
             const int m = (total - v0 < (uint32_t)kWave) ? (int)(total - v0) : kWave;
-            const int m4 = (m + 3) & ~3;  // padding slots hold far-away points
-            float sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-#pragma unroll 4
-            for (int j = 0; j < m4; ++j) {
-                const float4 c = win[w][j];  // same address in every lane: LDS broadcast
-                const float dx = c.x - q.x, dy = c.y - q.y, dz = c.z - q.z;
-                // FLANN L2_Simple: every product and sum rounded, in this order
-                const float xx = __fmul_rn(dx, dx), yy = __fmul_rn(dy, dy), zz = __fmul_rn(dz, dz);
-                const float d2 = __fadd_rn(__fadd_rn(xx, yy), zz);
-                if (d2 < g.r2) {  // RadiusResultSet::addPoint: strict
-                    ++cnt;
-                    sx += dx; sy += dy; sz += dz;
-                    sxx += xx; syy += yy; szz += zz;
-                    sxy = fmaf(dx, dy, sxy); sxz = fmaf(dx, dz, sxz); syz = fmaf(dy, dz, syz);
+            const int groups = (m + 3) >> 2;  // padding slots hold far-away points
+            // branch-free, two candidates per packed instruction (v_pk_*_f32): the
+            // inlier test becomes a 0/1 weight so nothing in the loop touches EXEC
+            v2f sn = {0, 0}, sx = {0, 0}, sy = {0, 0}, sz = {0, 0}, sxx = {0, 0}, sxy = {0, 0}, sxz = {0, 0},
+                syy = {0, 0}, syz = {0, 0}, szz = {0, 0};
+            float4 nx4 = *reinterpret_cast<const float4 *>(wx), ny4 = *reinterpret_cast<const float4 *>(wy),
+                   nz4 = *reinterpret_cast<const float4 *>(wz);
+            for (int gidx = 0; gidx < groups; ++gidx) {
+                const float4 cx4 = nx4, cy4 = ny4, cz4 = nz4;
+                const int nj = (gidx + 1 < groups) ? (gidx + 1) * 4 : 0;  // prefetch the next group (same address in every lane)
+                nx4 = *reinterpret_cast<const float4 *>(wx + nj);
+                ny4 = *reinterpret_cast<const float4 *>(wy + nj);
+                nz4 = *reinterpret_cast<const float4 *>(wz + nj);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const v2f cx = h ? (v2f){cx4.z, cx4.w} : (v2f){cx4.x, cx4.y};
+                    const v2f cy = h ? (v2f){cy4.z, cy4.w} : (v2f){cy4.x, cy4.y};
+                    const v2f cz = h ? (v2f){cz4.z, cz4.w} : (v2f){cz4.x, cz4.y};
+                    const v2f dx = cx - qx, dy = cy - qy, dz = cz - qz;
+                    // FLANN L2_Simple: every product and sum rounded, in this order
+                    const v2f xx = pk_mul_rn(dx, dx), yy = pk_mul_rn(dy, dy), zz = pk_mul_rn(dz, dz);
+                    const v2f d2 = pk_add_rn(pk_add_rn(xx, yy), zz);
+                    // RadiusResultSet::addPoint: strict d2 < r2
+                    const v2f wgt = {d2.x < r2v.x ? 1.0f : 0.0f, d2.y < r2v.y ? 1.0f : 0.0f};
+                    const v2f mx = wgt * dx, my = wgt * dy, mz = wgt * dz;
+                    sn += wgt;
+                    sx += mx; sy += my; sz += mz;
+                    sxx += mx * dx; syy += my * dy; szz += mz * dz;
+                    sxy += mx * dy; sxz += mx * dz; syz += my * dz;
                 }
             }
-            Sx += sx; Sy += sy; Sz += sz;
-            Sxx += sxx; Sxy += sxy; Sxz += sxz; Syy += syy; Syz += syz; Szz += szz;
+            // fold this window's fp32 partial sums into the fp64 totals
+            Sn += (double)(sn.x + sn.y);
+            Sx += (double)sx.x + (double)sx.y; Sy += (double)sy.x + (double)sy.y; Sz += (double)sz.x + (double)sz.y;
+            Sxx += (double)sxx.x + (double)sxx.y; Sxy += (double)sxy.x + (double)sxy.y;
+            Sxz += (double)sxz.x + (double)sxz.y; Syy += (double)syy.x + (double)syy.y;
+            Syz += (double)syz.x + (double)syz.y; Szz += (double)szz.x + (double)szz.y;
         }
+        const int cnt = (int)Sn;
 
         if (active) {
             const uint32_t dst = __float_as_uint(q.w);
@@ -246,9 +300,9 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
 
 uint32_t max_tiles(uint32_t n_cap, const GridParams &g)
 {
-    // every x-row adds at most one partially filled tile
-    const uint64_t rows = (uint64_t)g.ny * (uint64_t)g.nz;
-    const uint64_t extra = rows < n_cap ? rows : n_cap;
+    // every cell group adds at most one partially filled tile
+    const uint64_t groups = (uint64_t)g.ny * (uint64_t)g.nz * (uint64_t)((g.nx + kTileSpan - 1) / kTileSpan);
+    const uint64_t extra = groups < n_cap ? groups : n_cap;
     return (uint32_t)(n_cap / kWave + extra + 1);
 }
 
@@ -268,7 +322,7 @@ void launch_grid_and_normals(const GridParams &g, Slot &sl, uint32_t n_cap, bool
     hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(256), 0, s, (const float4 *)sl.crop4, (const uint32_t *)perm,
                        (const uint32_t *)&sl.ctr->n_cropped, sl.spts4);
     hipLaunchKernelGGL(k_build_tiles, dim3(gb), dim3(256), 0, s, (const uint32_t *)skeys, sl.ctr, (uint32_t)g.nx,
-                       sl.tiles, sl.tiles_cap);
+                       (uint32_t)kTileSpan, sl.tiles, sl.tiles_cap);
     // persistent grid: 8 blocks of 4 waves per CU fill every SIMD's 8 wave slots
     const uint32_t mt = max_tiles(n_cap, g);
     uint32_t nb = (mt + kNrWaves - 1) / kNrWaves;
