@@ -68,6 +68,33 @@ GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, flo
     return g;
 }
 
+// dense voxel table over the crop box, when it is small enough (see VoxDense)
+VoxDense make_vox_dense(float lo, float hi, double leaf, uint32_t n_cap, double own_lo, double own_hi)
+{
+    VoxDense vd;
+    memset(&vd, 0, sizeof(vd));
+    vd.inv_leaf = 1.0f / (float)leaf;
+    vd.lo = lo;
+    vd.own_lo = (float)own_lo;
+    vd.own_hi = (float)own_hi;
+    const double a = floor((double)(lo * vd.inv_leaf)), b = floor((double)(hi * vd.inv_leaf));
+    const double dim = b - a + 1.0;
+    if (std::isfinite(dim) && dim >= 1.0 && dim * dim * dim <= (double)kVoxDenseMaxCells && fabs(a) < 1e9) {
+        vd.enabled = 1;
+        vd.i_lo = (int32_t)a;
+        vd.dim = (int32_t)dim;
+        // power-of-two scale such that 2^28 points cannot overflow 63 bits; independent of the
+        // buffer capacity so that results do not depend on allocation history
+        const double ext = fmax((double)hi - (double)lo, 1e-30);
+        int k = (int)floor(log2(9.0e18 / (ext * 268435456.0)));
+        if (k > 40) k = 40;
+        if (k < 8 || n_cap > 268435456u) { vd.enabled = 0; k = 0; }
+        vd.scale = ldexp(1.0, k);
+        vd.inv_scale = ldexp(1.0, -k);
+    }
+    return vd;
+}
+
 int bits_for(uint64_t count)
 {
     int b = 1;
@@ -115,7 +142,7 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
     GM_HIP(ctx, dmalloc(sl.vox_nn, cap)); GM_HIP(ctx, dmalloc(sl.labels, cap));
     sl.tiles_cap = cap + cap / kWave + 2u;  // every tile holds >= 1 point; n/64 full ones at most
     GM_HIP(ctx, dmalloc(sl.tiles, sl.tiles_cap));
-    sl.blk_cap = compact_blocks(cap) + 1;
+    sl.blk_cap = compact_blocks(cap > kVoxDenseMaxCells ? cap : kVoxDenseMaxCells) + 1;
     GM_HIP(ctx, dmalloc(sl.blk, sl.blk_cap));
     sl.sort.hist_cap = radix_hist_entries(cap);
     GM_HIP(ctx, dmalloc(sl.sort.hist, sl.sort.hist_cap));
@@ -177,17 +204,38 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud)
     const float lo = (float)(-cf.boxFilterBound), hi = (float)cf.boxFilterBound;
     const float ext = hi - lo;
     const GridParams g = make_grid(lo, lo, lo, ext, ext, ext, cf.neighborRadius);
+    VoxDense vd;
+    memset(&vd, 0, sizeof(vd));
+    vd.own_lo = (float)ctx->own_lo;
+    vd.own_hi = (float)ctx->own_hi;
+    if ((cf.flags & GM_CFG_VOXEL_GRID) && !ctx->force_voxel_sort)
+        vd = make_vox_dense(lo, hi, cf.voxelGridLeafSize, sl.cap, ctx->own_lo, ctx->own_hi);
+    if (vd.enabled) {
+        const uint32_t cells = (uint32_t)vd.dim * vd.dim * vd.dim;
+        if (cells > sl.vox_table_cap) {
+            GM_HIP(ctx, hipStreamSynchronize(s));
+            hipFree(sl.vox_table);
+            sl.vox_table = nullptr;
+            GM_HIP(ctx, dmalloc(sl.vox_table, cells));
+            sl.vox_table_cap = cells;
+        }
+        GM_HIP(ctx, hipMemsetAsync(sl.vox_table, 0, (size_t)cells * sizeof(VoxCell), s));
+    }
     launch_crop(rows, n, lo, hi, g, sl, s);
     record(ctx, sl, 2);
-    launch_grid_and_normals(g, sl, n, (cf.flags & GM_CFG_KEEP_COUNTS) != 0, s);
+    launch_grid_and_normals(g, vd, sl, n, (cf.flags & GM_CFG_KEEP_COUNTS) != 0, s);
     record(ctx, sl, 3);  // end of grid+normals; the kernel alone is bracketed by ev_k0/ev_k1
     launch_compact_valid(sl, n, (float)ctx->own_lo, (float)ctx->own_hi, s);
     record(ctx, sl, 4);
     const uint32_t nparts = launch_scatter_partials(sl.vnorm4, &sl.ctr->n_valid, n, cf.weightingFactor, sl, s);
     record(ctx, sl, 5);
     if (cf.flags & GM_CFG_VOXEL_GRID) {
-        launch_minmax(sl.valid4, &sl.ctr->n_valid, n, sl.ctr, s);
-        launch_voxel_grid(sl, n, (float)cf.voxelGridLeafSize, voxel_key_bits(lo, hi, cf.voxelGridLeafSize), s);
+        if (vd.enabled) {
+            launch_voxel_dense_finalize(vd, sl, s);
+        } else {  // lattice too large for a table: min/max -> keys -> sort -> segmented mean
+            launch_minmax(sl.valid4, &sl.ctr->n_valid, n, sl.ctr, s);
+            launch_voxel_grid(sl, n, (float)cf.voxelGridLeafSize, voxel_key_bits(lo, hi, cf.voxelGridLeafSize), s);
+        }
     }
     record(ctx, sl, 6);
     launch_frame_finalize(nparts, sl, s);
@@ -331,6 +379,7 @@ gm_status gm_create(const gm_config *cfg, gm_ctx **out)
     if (ctx->n_slots > 16) ctx->n_slots = 16;
     ctx->own_lo = -std::numeric_limits<double>::infinity();
     ctx->own_hi = std::numeric_limits<double>::infinity();
+    ctx->force_voxel_sort = getenv("GM_VOXEL_SORT_PATH") != nullptr;  // tests: exercise the general path
     gm_status st = GM_OK;
     auto body = [&]() -> gm_status {
         GM_HIP(ctx, hipSetDevice(ctx->device));
@@ -382,7 +431,7 @@ void gm_destroy(gm_ctx *ctx)
             Slot &sl = ctx->slots[i];
             if (sl.stream) hipStreamSynchronize(sl.stream);
             free_slot_buffers(sl);
-            hipFree(sl.ctr); hipFree(sl.voxp); hipFree(sl.d_out); hipFree(sl.partials);
+            hipFree(sl.ctr); hipFree(sl.voxp); hipFree(sl.d_out); hipFree(sl.partials); hipFree(sl.vox_table);
             hipFree(sl.hyp); hipFree(sl.hyp_counts); hipFree(sl.seg_mom);
             if (sl.h_out) hipHostFree(sl.h_out);
             for (int k = 0; k <= GM_N_STAGES; ++k) if (sl.ev[k]) hipEventDestroy(sl.ev[k]);
@@ -536,7 +585,11 @@ gm_status gm_get_normals_stage(gm_ctx *ctx, const float *xyz, uint32_t n, double
     const GridParams g = make_grid(mn[0], mn[1], mn[2], mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], radius);
     const float big = std::numeric_limits<float>::max();
     launch_crop(rows, n, -big, big, g, sl, sl.stream);  // drops non-finite rows only
-    launch_grid_and_normals(g, sl, n, (ctx->cfg.flags & GM_CFG_KEEP_COUNTS) != 0, sl.stream);
+    VoxDense vd_off;
+    memset(&vd_off, 0, sizeof(vd_off));
+    vd_off.own_lo = -std::numeric_limits<float>::infinity();
+    vd_off.own_hi = std::numeric_limits<float>::infinity();
+    launch_grid_and_normals(g, vd_off, sl, n, (ctx->cfg.flags & GM_CFG_KEEP_COUNTS) != 0, sl.stream);
     launch_compact_valid(sl, n, -std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity(), sl.stream);
     uint32_t m[2] = {0, 0};
     GM_HIP(ctx, hipMemcpyAsync(m, &sl.ctr->n_cropped, 8, hipMemcpyDeviceToHost, sl.stream));

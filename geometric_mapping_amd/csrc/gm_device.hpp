@@ -43,6 +43,24 @@ struct GridParams {
     float r2;           // (float)(radius*radius): KdTreeFLANN::radiusSearch's cast
 };
 
+// Dense voxel table (fast path of the VoxelGrid stage): when the crop box bounds
+// the voxel lattice to a small table, per-voxel sums are accumulated as exact
+// 64-bit fixed-point integers (order-free, so bit-reproducible) right where the
+// normals are produced, and the sorted output is a compaction of the table.
+struct VoxCell {
+    unsigned long long sx, sy, sz;  // sum of (coord - lo) * scale, rounded to integer per point
+    uint32_t cnt, pad;
+};
+struct VoxDense {
+    uint32_t enabled;
+    int32_t i_lo;        // floor(lo * inv_leaf): lattice index of the box's lower face
+    int32_t dim;         // lattice cells per axis covered by the box
+    float inv_leaf;      // 1 / (float)leaf, as pcl::VoxelGrid computes it
+    float lo;            // lower face of the crop box
+    float own_lo, own_hi;// slab ownership (multi-GPU), +-inf otherwise
+    double scale, inv_scale;
+};
+
 struct FrameOut {        // device -> host result record (one small D2H per frame)
     DevCounters ctr;
     float evals[3];

@@ -50,6 +50,8 @@ struct Slot {
     SortScratch sort = {};
     uint32_t *seg_start = nullptr;
     float4 *vox4 = nullptr;       // voxel centroids: x,y,z,count
+    VoxCell *vox_table = nullptr; // dense voxel table (fast path)
+    uint32_t vox_table_cap = 0;   // cells
     int32_t *vox_nn = nullptr;
     double *partials = nullptr;   // [kScatterBlocks][6]
     uint8_t *labels = nullptr;
@@ -75,6 +77,7 @@ struct gm_ctx {
     uint32_t n_slots = 1;
     gm::Slot *slots = nullptr;
     double own_lo, own_hi;
+    bool force_voxel_sort = false;
     std::string err;
 };
 
@@ -93,7 +96,8 @@ int launch_radix_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint
 void launch_exclusive_scan(uint32_t *data, uint32_t count, uint32_t *total_out, uint32_t *total_out2, hipStream_t s);
 uint32_t radix_hist_entries(uint32_t n_cap);
 // k_normals.hip
-void launch_grid_and_normals(const GridParams &g, Slot &sl, uint32_t n_cap, bool keep_counts, hipStream_t s);
+void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, uint32_t n_cap, bool keep_counts,
+                             hipStream_t s);
 uint32_t max_tiles(uint32_t n_cap, const GridParams &g);
 // k_frame.hip
 void launch_compact_valid(Slot &sl, uint32_t n_cap, float own_lo, float own_hi, hipStream_t s);
@@ -103,6 +107,8 @@ uint32_t launch_scatter_partials(const float4 *vnorm4, const uint32_t *n_ptr, ui
 void launch_frame_finalize(uint32_t n_partials, Slot &sl, hipStream_t s);
 // k_voxel.hip
 void launch_voxel_grid(Slot &sl, uint32_t n_cap, float leaf, int key_bits, hipStream_t s);
+void launch_voxel_dense_finalize(const VoxDense &vd, Slot &sl, hipStream_t s);
+constexpr uint32_t kVoxDenseMaxCells = 1u << 18;
 void launch_minmax(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, DevCounters *ctr, hipStream_t s);
 
 }  // namespace gm

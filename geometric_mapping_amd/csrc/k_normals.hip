@@ -70,29 +70,51 @@ __global__ __launch_bounds__(256) void k_gather_sorted(const float4 *__restrict_
 // Bounding the x-extent of a tile bounds its candidate count (sparse rows would
 // otherwise produce tiles spanning tens of cells: a 20x outlier that the whole
 // grid then waits for).
-__global__ __launch_bounds__(256) void k_build_tiles(const uint32_t *__restrict__ skeys,
-                                                     DevCounters *__restrict__ ctr, uint32_t nx, uint32_t span,
-                                                     uint2 *__restrict__ tiles, uint32_t tiles_cap)
+__global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict__ skeys,
+                                                      DevCounters *__restrict__ ctr, uint32_t nx, uint32_t span,
+                                                      uint2 *__restrict__ tiles, uint32_t tiles_cap)
 {
+    __shared__ uint32_t wtot[1024 / kWave];
+    __shared__ uint32_t block_base;
     const uint32_t n = ctr->n_cropped;
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    const uint32_t s = blockIdx.x * 1024u + threadIdx.x;
+    if (blockIdx.x * 1024u >= n) return;  // uniform per block
+    uint32_t cnt = 0, e = 0;
+    if (s < n) {
         const uint32_t key = skeys[s];
         const uint32_t row = key / nx;
         const uint32_t gx = (key - row * nx) / span;
+        bool start = true;
         if (s != 0) {
             const uint32_t pk = skeys[s - 1];
             const uint32_t prow = pk / nx;
-            if (prow == row && (pk - prow * nx) / span == gx) continue;  // not the first point of its group
+            start = !(prow == row && (pk - prow * nx) / span == gx);
         }
-        // one past the last point of this group
-        uint32_t kend = row * nx + (gx + 1u) * span;
-        if (kend > (row + 1u) * nx) kend = (row + 1u) * nx;
-        const uint32_t e = lower_bound_u32(skeys, n, kend);
-        const uint32_t cnt = (e - s + kWave - 1) / kWave;
-        uint32_t t = atomicAdd(&ctr->n_tiles, cnt);
-        for (uint32_t b = s; b < e; b += kWave, ++t)
-            if (t < tiles_cap) tiles[t] = make_uint2(b, (e - b < (uint32_t)kWave) ? e - b : (uint32_t)kWave);
+        if (start) {
+            // one past the last point of this group
+            uint32_t kend = row * nx + (gx + 1u) * span;
+            if (kend > (row + 1u) * nx) kend = (row + 1u) * nx;
+            e = lower_bound_u32(skeys, n, kend);
+            cnt = (e - s + kWave - 1) / kWave;
+        }
     }
+    // block-wide exclusive prefix of the tile counts, ONE atomic per block for the base
+    const uint32_t inc = wave_inclusive_scan(cnt);
+    const int w = threadIdx.x / kWave;
+    if (lane_id() == kWave - 1) wtot[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 1024 / kWave; ++k) {
+        const uint32_t c = wtot[k];
+        if (k < w) woff += c;
+        total += c;
+    }
+    if (threadIdx.x == 0) block_base = total ? atomicAdd(&ctr->n_tiles, total) : 0u;
+    __syncthreads();
+    uint32_t t = block_base + woff + inc - cnt;
+    for (uint32_t b = s; cnt && b < e; b += kWave, ++t)
+        if (t < tiles_cap) tiles[t] = make_uint2(b, (e - b < (uint32_t)kWave) ? e - b : (uint32_t)kWave);
 }
 
 // ---- smallest eigenpair of a symmetric PSD 3x3, fp64 ----------------------------
@@ -159,7 +181,8 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
                                                         const uint2 *__restrict__ tiles,
                                                         DevCounters *__restrict__ ctr, GridParams g,
                                                         uint32_t tiles_cap, float4 *__restrict__ normals4,
-                                                        int32_t *__restrict__ counts)
+                                                        int32_t *__restrict__ counts, VoxDense vd,
+                                                        VoxCell *__restrict__ vox_table)
 {
     // candidate window, one per wave, SoA so that one broadcast ds_read_b128 feeds
     // the x (or y, z) of FOUR candidates to every lane
@@ -273,6 +296,7 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
         }
         const int cnt = (int)Sn;
 
+        bool vox_ok = false;
         if (active) {
             const uint32_t dst = __float_as_uint(q.w);
             float4 out = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
@@ -290,10 +314,46 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
                     const double ct = -((double)q.x * nv[0] + (double)q.y * nv[1] + (double)q.z * nv[2]);
                     const double sgn = (ct < 0.0) ? -1.0 : 1.0;
                     out = make_float4((float)(sgn * nv[0]), (float)(sgn * nv[1]), (float)(sgn * nv[2]), (float)curv);
+                    vox_ok = finite3(out.x, out.y, out.z) && q.x >= vd.own_lo && q.x < vd.own_hi;
                 }
             }
             normals4[dst] = out;
             if (counts) counts[dst] = cnt;
+        }
+
+        // ---- VoxelGrid fast path: points of a tile are spatial neighbours, so they fall
+        // into one to three voxels; reduce by voxel inside the wave, then one set of
+        // integer atomics per (wave, voxel).  (pcl::VoxelGrid, src/tunnel_processing.cpp:217-220)
+        if (vd.enabled) {
+            uint32_t vkey = 0;
+            unsigned long long fx = 0, fy = 0, fz = 0;
+            if (vox_ok) {
+                const int ix = (int)floorf(q.x * vd.inv_leaf) - vd.i_lo;
+                const int iy = (int)floorf(q.y * vd.inv_leaf) - vd.i_lo;
+                const int iz = (int)floorf(q.z * vd.inv_leaf) - vd.i_lo;
+                vkey = (uint32_t)((iz * vd.dim + iy) * vd.dim + ix);
+                fx = (unsigned long long)(((double)q.x - (double)vd.lo) * vd.scale + 0.5);
+                fy = (unsigned long long)(((double)q.y - (double)vd.lo) * vd.scale + 0.5);
+                fz = (unsigned long long)(((double)q.z - (double)vd.lo) * vd.scale + 0.5);
+            }
+            uint64_t remaining = __ballot(vox_ok);
+            while (remaining) {  // wave-uniform loop
+                const int leader = (int)__builtin_ctzll(remaining);
+                const uint32_t k = __shfl(vkey, leader, kWave);
+                const bool mine = vox_ok && vkey == k;
+                const uint64_t same = __ballot(mine);
+                const unsigned long long ax = wave_sum(mine ? fx : 0ull);
+                const unsigned long long ay = wave_sum(mine ? fy : 0ull);
+                const unsigned long long az = wave_sum(mine ? fz : 0ull);
+                if (lane == leader) {
+                    VoxCell *cell = vox_table + k;
+                    atomicAdd(&cell->sx, ax);
+                    atomicAdd(&cell->sy, ay);
+                    atomicAdd(&cell->sz, az);
+                    atomicAdd(&cell->cnt, (uint32_t)__popcll(same));
+                }
+                remaining &= ~same;
+            }
         }
     }
 }
@@ -306,7 +366,8 @@ uint32_t max_tiles(uint32_t n_cap, const GridParams &g)
     return (uint32_t)(n_cap / kWave + extra + 1);
 }
 
-void launch_grid_and_normals(const GridParams &g, Slot &sl, uint32_t n_cap, bool keep_counts, hipStream_t s)
+void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, uint32_t n_cap, bool keep_counts,
+                             hipStream_t s)
 {
     if (n_cap == 0) return;
     // bits needed by the largest cell key
@@ -321,7 +382,7 @@ void launch_grid_and_normals(const GridParams &g, Slot &sl, uint32_t n_cap, bool
     const uint32_t gb = (n_cap + 255) / 256 < 2048 ? (n_cap + 255) / 256 : 2048;
     hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(256), 0, s, (const float4 *)sl.crop4, (const uint32_t *)perm,
                        (const uint32_t *)&sl.ctr->n_cropped, sl.spts4);
-    hipLaunchKernelGGL(k_build_tiles, dim3(gb), dim3(256), 0, s, (const uint32_t *)skeys, sl.ctr, (uint32_t)g.nx,
+    hipLaunchKernelGGL(k_build_tiles, dim3((n_cap + 1023) / 1024), dim3(1024), 0, s, (const uint32_t *)skeys, sl.ctr, (uint32_t)g.nx,
                        (uint32_t)kTileSpan, sl.tiles, sl.tiles_cap);
     // persistent grid: 8 blocks of 4 waves per CU fill every SIMD's 8 wave slots
     const uint32_t mt = max_tiles(n_cap, g);
@@ -330,7 +391,7 @@ void launch_grid_and_normals(const GridParams &g, Slot &sl, uint32_t n_cap, bool
     hipEventRecord(sl.ev_k0, s);
     hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), 0, s, (const float4 *)sl.spts4, (const uint32_t *)skeys,
                        (const uint2 *)sl.tiles, sl.ctr, g, sl.tiles_cap, sl.normals4,
-                       keep_counts ? sl.counts : (int32_t *)nullptr);
+                       keep_counts ? sl.counts : (int32_t *)nullptr, vd, sl.vox_table);
     hipEventRecord(sl.ev_k1, s);
 }
 

@@ -1,101 +1,175 @@
-// k_sort.hip -- stable LSD radix sort of (key, value) pairs, 8 bits per pass.
+// k_sort.hip -- stable LSD radix sort of (key, value) pairs, up to 11 bits per pass.
 //
-// Utility for the two binning steps of the path: search-grid cell keys (stands
-// in for the FLANN kd-tree build, /root/reference src/tunnel_processing.cpp:62-70)
-// and voxel keys (pcl::VoxelGrid's std::sort, src/tunnel_processing.cpp:217-220).
-// Stable on purpose: the order of points inside a cell fixes the fp32 summation
-// order downstream, so results are bit-reproducible run to run.
+// Utility for the binning steps of the path: search-grid cell keys (stands in
+// for the FLANN kd-tree build, /root/reference src/tunnel_processing.cpp:62-70)
+// and, on the fallback path, voxel keys (pcl::VoxelGrid's std::sort,
+// src/tunnel_processing.cpp:217-220).  Stable on purpose: the order of points
+// inside a cell fixes the fp32 summation order downstream, so results are
+// bit-reproducible run to run.
 //
-// Per pass: per-block digit histogram -> one global exclusive scan (digit-major)
-// -> stable scatter.  Inside a block the rank of an item among equal digits is
-// wave-ballot "match" (8 ballots) + a [waves][256] LDS table.  The element
-// count is device-resident; blocks past the end exit after publishing zeros.
-#include "gm_compact.hpp"
+// Per pass, two launches:
+//   k_rs_hist    per-block digit histogram -> hist[block][digit] (plain stores) and
+//                digit totals (one atomicAdd per block and digit, integer: order-free)
+//   k_rs_scatter each block derives its own base offsets -- exclusive scan of the
+//                digit totals (block-local, 2^bits entries) plus the sum of the
+//                histogram rows of the blocks before it (coalesced row reads from
+//                L2) -- then ranks its items stably: wave-ballot "match" for the rank
+//                among equal digits inside a wave, a [waves][bins] LDS table across
+//                waves, running per-digit bases across rounds.
+// There is no global scan kernel: the block count is kept <= ~512 by growing the
+// per-block tile with n, so the row sums stay a few tens of MB of L2 traffic.
+// The element count is device-resident; blocks past the end publish zero rows.
 #include "gm_internal.hpp"
 
 namespace gm {
 
 constexpr int kRsThreads = 256;
-constexpr int kRsItems = 16;
-constexpr int kRsTile = kRsThreads * kRsItems;
-constexpr int kRsBits = 8;
-constexpr int kRsBins = 1 << kRsBits;
 constexpr int kRsWaves = kRsThreads / kWave;
+constexpr int kRsMaxBits = 11;
+constexpr int kRsMaxPasses = 4;
 
-static inline uint32_t rs_blocks(uint32_t n) { return (n + kRsTile - 1) / kRsTile; }
-uint32_t radix_hist_entries(uint32_t n_cap) { return kRsBins * (rs_blocks(n_cap) + 1); }
+static inline uint32_t rs_items(uint32_t n_cap)
+{
+    // items per thread: tile = 256 * items; aim for <= 512 blocks, at least 16 items
+    uint32_t items = (n_cap + 512u * kRsThreads - 1) / (512u * kRsThreads);
+    return items < 16 ? 16 : items;
+}
+static inline uint32_t rs_blocks(uint32_t n_cap)
+{
+    const uint32_t tile = rs_items(n_cap) * kRsThreads;
+    return (n_cap + tile - 1) / tile;
+}
+uint32_t radix_hist_entries(uint32_t n_cap)
+{
+    return (1u << kRsMaxBits) * (rs_blocks(n_cap) + 1) + kRsMaxPasses * (1u << kRsMaxBits);
+}
 
+template <int BITS>
 __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const uint32_t *__restrict__ keys,
                                                         const uint32_t *__restrict__ n_ptr, int shift,
-                                                        uint32_t *__restrict__ hist, uint32_t nblocks)
+                                                        uint32_t items, uint32_t *__restrict__ hist,
+                                                        uint32_t *__restrict__ totals)
 {
-    __shared__ uint32_t h[kRsBins];
+    constexpr int BINS = 1 << BITS;
+    __shared__ uint32_t h[BINS];
     const uint32_t n = *n_ptr;
-    const uint32_t base = blockIdx.x * kRsTile;
-    h[threadIdx.x] = 0;
+    const uint32_t base = blockIdx.x * items * kRsThreads;
+    for (int k = threadIdx.x; k < BINS; k += kRsThreads) h[k] = 0;
     __syncthreads();
     if (base < n) {
-#pragma unroll 4
-        for (int j = 0; j < kRsItems; ++j) {
-            uint32_t i = base + j * kRsThreads + threadIdx.x;
-            if (i < n) atomicAdd(&h[(keys[i] >> shift) & (kRsBins - 1)], 1u);
+        for (uint32_t j = 0; j < items; ++j) {
+            const uint32_t i = base + j * kRsThreads + threadIdx.x;
+            if (i < n) atomicAdd(&h[(keys[i] >> shift) & (BINS - 1)], 1u);
         }
     }
     __syncthreads();
-    hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    for (int k = threadIdx.x; k < BINS; k += kRsThreads) {
+        const uint32_t c = h[k];
+        hist[(size_t)blockIdx.x * BINS + k] = c;
+        if (c) atomicAdd(&totals[k], c);
+    }
 }
 
+template <int BITS>
 __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
                                                            const uint32_t *__restrict__ vals_in,
                                                            uint32_t *__restrict__ keys_out,
                                                            uint32_t *__restrict__ vals_out,
                                                            const uint32_t *__restrict__ n_ptr, int shift,
-                                                           const uint32_t *__restrict__ hist, uint32_t nblocks)
+                                                           uint32_t items, const uint32_t *__restrict__ hist,
+                                                           const uint32_t *__restrict__ totals)
 {
-    __shared__ uint32_t base_of[kRsBins];
-    __shared__ uint32_t wtab[kRsWaves][kRsBins];
+    constexpr int BINS = 1 << BITS;
+    constexpr int PER = BINS / kRsThreads;  // digits owned by one thread (BITS >= 8)
+    __shared__ uint32_t wtab[kRsWaves][BINS];  // per wave: digit count, then next output slot
+    __shared__ uint32_t wsum[kRsWaves];
     const uint32_t n = *n_ptr;
-    const uint32_t tile = blockIdx.x * kRsTile;
+    const uint32_t tile = blockIdx.x * items * kRsThreads;
     if (tile >= n) return;  // uniform per block
     const int w = threadIdx.x / kWave;
-    base_of[threadIdx.x] = hist[threadIdx.x * nblocks + blockIdx.x];
-    for (int j = 0; j < kRsItems; ++j) {
-        const uint32_t i = tile + j * kRsThreads + threadIdx.x;
+    const int lane = lane_id();
+    // wave w owns the contiguous chunk [wbase, wbase + items*64) of the tile, so every
+    // item of wave w precedes every item of wave w+1: ranks need no per-round barrier
+    const uint32_t wbase = tile + (uint32_t)w * items * kWave;
+
+    for (int k = threadIdx.x; k < kRsWaves * BINS; k += kRsThreads) (&wtab[0][0])[k] = 0;
+    __syncthreads();
+    for (uint32_t j = 0; j < items; ++j) {
+        const uint32_t i = wbase + j * kWave + lane;
+        if (i < n) atomicAdd(&wtab[w][(keys_in[i] >> shift) & (BINS - 1)], 1u);
+    }
+    // ---- start of this block's span for every digit: exclusive scan of the digit
+    //      totals + histogram rows of the blocks before this one
+    uint32_t tot[PER], before[PER];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        tot[k] = totals[threadIdx.x * PER + k];  // thread t owns digits [t*PER, t*PER+PER)
+        tsum += tot[k];
+        before[k] = 0;
+    }
+    for (uint32_t b = 0; b < blockIdx.x; ++b) {
+        const uint32_t *row = hist + (size_t)b * BINS + threadIdx.x * PER;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) before[k] += row[k];
+    }
+    const uint32_t inc = wave_inclusive_scan(tsum);
+    if (lane == kWave - 1) wsum[w] = inc;
+    __syncthreads();  // also: all per-wave digit counts are in wtab
+    uint32_t run = inc - tsum;
+#pragma unroll
+    for (int k = 0; k < kRsWaves; ++k) if (k < w) run += wsum[k];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int dig = threadIdx.x * PER + k;
+        uint32_t slot = run + before[k];
+#pragma unroll
+        for (int ww = 0; ww < kRsWaves; ++ww) {  // counts -> first output slot of each wave
+            const uint32_t c = wtab[ww][dig];
+            wtab[ww][dig] = slot;
+            slot += c;
+        }
+        run += tot[k];
+    }
+    __syncthreads();
+
+    for (uint32_t j = 0; j < items; ++j) {
+        const uint32_t i = wbase + j * kWave + lane;
         const bool valid = i < n;
         const uint32_t key = valid ? keys_in[i] : 0xFFFFFFFFu;
-        const uint32_t d = (key >> shift) & (kRsBins - 1);
+        const uint32_t d = (key >> shift) & (BINS - 1);
         // lanes of this wave holding the same digit
         uint64_t peers = __ballot(valid);
+        if (peers == 0) break;  // wave-uniform: the rest of the chunk is past the end
 #pragma unroll
-        for (int b = 0; b < kRsBits; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             const bool bit = (d >> b) & 1u;
             const uint64_t m = __ballot(bit);
             peers &= bit ? m : ~m;
         }
         const uint32_t rank = (uint32_t)__popcll(peers & lanemask_lt());
-#pragma unroll
-        for (int k = 0; k < kRsBins / kWave; ++k) wtab[w][k * kWave + lane_id()] = 0;
-        wave_lds_fence();
-        if (valid && rank == 0) wtab[w][d] = (uint32_t)__popcll(peers);
-        __syncthreads();
-        {   // thread t owns digit t: turn per-wave counts into per-wave global offsets
-            uint32_t run = base_of[threadIdx.x];
-#pragma unroll
-            for (int k = 0; k < kRsWaves; ++k) {
-                uint32_t c = wtab[k][threadIdx.x];
-                wtab[k][threadIdx.x] = run;
-                run += c;
-            }
-            base_of[threadIdx.x] = run;
+        uint32_t slot = 0;
+        if (valid && rank == 0) {  // lowest lane of each digit group claims the group's slots
+            slot = wtab[w][d];
+            wtab[w][d] = slot + (uint32_t)__popcll(peers);
         }
-        __syncthreads();
+        wave_lds_fence();
+        slot = __shfl(slot, valid ? (int)__builtin_ctzll(peers) : lane, kWave);
         if (valid) {
-            const uint32_t dst = wtab[w][d] + rank;
+            const uint32_t dst = slot + rank;
             keys_out[dst] = key;
             vals_out[dst] = vals_in ? vals_in[i] : i;
         }
-        __syncthreads();
     }
+}
+
+template <int BITS>
+static void rs_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, const uint32_t *n_ptr,
+                    int shift, uint32_t items, uint32_t nb, uint32_t *hist, uint32_t *totals, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_rs_hist<BITS>, dim3(nb), dim3(kRsThreads), 0, s, kin, n_ptr, shift, items, hist, totals);
+    hipLaunchKernelGGL(k_rs_scatter<BITS>, dim3(nb), dim3(kRsThreads), 0, s, kin, vin, kout, vout, n_ptr, shift, items,
+                       (const uint32_t *)hist, (const uint32_t *)totals);
 }
 
 int launch_radix_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
@@ -103,18 +177,31 @@ int launch_radix_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint
 {
     const uint32_t nb = rs_blocks(n_cap);
     if (nb == 0) return 0;
-    int passes = (key_bits + kRsBits - 1) / kRsBits;
-    if (passes < 1) passes = 1;
-    uint32_t *kin = keys_a, *vin = nullptr /* first pass: value = index */, *kout = keys_b, *vout = vals_b;
+    if (key_bits < 1) key_bits = 1;
+    if (key_bits > 32) key_bits = 32;
+    int passes = (key_bits + kRsMaxBits - 1) / kRsMaxBits;
+    int bits = (key_bits + passes - 1) / passes;  // spread the bits evenly
+    if (bits < 8) bits = 8;
+    const uint32_t items = rs_items(n_cap);
+    uint32_t *hist = sc.hist;
+    uint32_t *totals = sc.hist + (size_t)(1u << kRsMaxBits) * (nb + 1);
+    hipMemsetAsync(totals, 0, sizeof(uint32_t) * kRsMaxPasses * (1u << kRsMaxBits), s);
+    const uint32_t *kin = keys_a, *vin = nullptr /* first pass: value = index */;
+    uint32_t *kout = keys_b, *vout = vals_b;
     for (int p = 0; p < passes; ++p) {
-        const int shift = p * kRsBits;
-        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(kRsThreads), 0, s, (const uint32_t *)kin, n_ptr, shift, sc.hist, nb);
-        launch_exclusive_scan(sc.hist, kRsBins * nb, nullptr, nullptr, s);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(kRsThreads), 0, s, (const uint32_t *)kin,
-                           (const uint32_t *)vin, kout, vout, n_ptr, shift, (const uint32_t *)sc.hist, nb);
-        // ping-pong
+        const int shift = p * bits;
+        uint32_t *tot = totals + (size_t)p * (1u << kRsMaxBits);
+        switch (bits) {
+        case 8: rs_pass<8>(kin, vin, kout, vout, n_ptr, shift, items, nb, hist, tot, s); break;
+        case 9: rs_pass<9>(kin, vin, kout, vout, n_ptr, shift, items, nb, hist, tot, s); break;
+        case 10: rs_pass<10>(kin, vin, kout, vout, n_ptr, shift, items, nb, hist, tot, s); break;
+        default: rs_pass<11>(kin, vin, kout, vout, n_ptr, shift, items, nb, hist, tot, s); break;
+        }
         if (p == 0) { kin = keys_b; vin = vals_b; kout = keys_a; vout = vals_a; }
-        else { uint32_t *t = kin; kin = kout; kout = t; t = vin; vin = vout; vout = t; }
+        else {
+            const uint32_t *t = kin; kin = kout; kout = (uint32_t *)t;
+            t = vin; vin = vout; vout = (uint32_t *)t;
+        }
     }
     return (passes & 1) ? 1 : 0;
 }

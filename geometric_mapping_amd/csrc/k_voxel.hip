@@ -94,6 +94,37 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(const float4 *__restric
     }
 }
 
+// ---- dense-table fast path: ascending table order IS ascending pcl key order ----
+struct DensePred {
+    const VoxCell *__restrict__ table;
+    __device__ __forceinline__ bool operator()(uint32_t i) const { return table[i].cnt != 0; }
+};
+struct DenseEmit {
+    const VoxCell *__restrict__ table;
+    float4 *__restrict__ vox4;
+    double lo, inv_scale;
+    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst) const
+    {
+        const VoxCell c = table[src];
+        const double inv = inv_scale / (double)c.cnt;
+        vox4[dst] = make_float4((float)(lo + (double)c.sx * inv), (float)(lo + (double)c.sy * inv),
+                                (float)(lo + (double)c.sz * inv), (float)c.cnt);
+    }
+};
+
+void launch_voxel_dense_finalize(const VoxDense &vd, Slot &sl, hipStream_t s)
+{
+    const uint32_t cells = (uint32_t)vd.dim * vd.dim * vd.dim;
+    const uint32_t nb = compact_blocks(cells);
+    DensePred pred{sl.vox_table};
+    DenseEmit emit{sl.vox_table, sl.vox4, (double)vd.lo, vd.inv_scale};
+    hipLaunchKernelGGL(k_compact_count<DensePred>, dim3(nb), dim3(kCpThreads), 0, s, pred, (const uint32_t *)nullptr,
+                       cells, sl.blk);
+    launch_exclusive_scan(sl.blk, nb, &sl.ctr->n_voxels, nullptr, s);
+    hipLaunchKernelGGL((k_compact_scatter<DensePred, DenseEmit>), dim3(nb), dim3(kCpThreads), 0, s, pred, emit,
+                       (const uint32_t *)nullptr, cells, (const uint32_t *)sl.blk);
+}
+
 void launch_voxel_grid(Slot &sl, uint32_t n_cap, float leaf, int key_bits, hipStream_t s)
 {
     hipLaunchKernelGGL(k_voxel_setup, dim3(1), dim3(64), 0, s, (const DevCounters *)sl.ctr, leaf, sl.voxp);
