@@ -23,16 +23,18 @@
 
 namespace gm {
 
-constexpr int kRsThreads = 256;
-constexpr int kRsWaves = kRsThreads / kWave;
+constexpr int kRsThreads = 1024;
+constexpr int kRsWaves = kRsThreads / kWave;  // 16
 constexpr int kRsMaxBits = 11;
 constexpr int kRsMaxPasses = 4;
+constexpr int kRsBatch = 8;  // keys a lane keeps in registers at a time
 
 static inline uint32_t rs_items(uint32_t n_cap)
 {
-    // items per thread: tile = 256 * items; aim for <= 512 blocks, at least 16 items
-    uint32_t items = (n_cap + 512u * kRsThreads - 1) / (512u * kRsThreads);
-    return items < 16 ? 16 : items;
+    // items per thread (multiple of kRsBatch): tile = 1024 * items; aim for <= 256 blocks
+    uint32_t items = (n_cap + 256u * kRsThreads - 1) / (256u * kRsThreads);
+    items = (items + kRsBatch - 1) / kRsBatch * kRsBatch;
+    return items < (uint32_t)kRsBatch ? (uint32_t)kRsBatch : items;
 }
 static inline uint32_t rs_blocks(uint32_t n_cap)
 {
@@ -57,9 +59,18 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_hist(const uint32_t *__restri
     for (int k = threadIdx.x; k < BINS; k += kRsThreads) h[k] = 0;
     __syncthreads();
     if (base < n) {
-        for (uint32_t j = 0; j < items; ++j) {
-            const uint32_t i = base + j * kRsThreads + threadIdx.x;
-            if (i < n) atomicAdd(&h[(keys[i] >> shift) & (BINS - 1)], 1u);
+        for (uint32_t j0 = 0; j0 < items; j0 += kRsBatch) {
+            uint32_t kk[kRsBatch];
+#pragma unroll
+            for (int u = 0; u < kRsBatch; ++u) {  // kRsBatch independent loads in flight
+                const uint32_t i = base + (j0 + u) * kRsThreads + threadIdx.x;
+                kk[u] = (i < n) ? keys[i] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < kRsBatch; ++u) {
+                const uint32_t i = base + (j0 + u) * kRsThreads + threadIdx.x;
+                if (i < n) atomicAdd(&h[(kk[u] >> shift) & (BINS - 1)], 1u);
+            }
         }
     }
     __syncthreads();
@@ -80,7 +91,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__res
                                                            const uint32_t *__restrict__ totals)
 {
     constexpr int BINS = 1 << BITS;
-    constexpr int PER = BINS / kRsThreads;  // digits owned by one thread (BITS >= 8)
+    constexpr int PER = (BINS + kRsThreads - 1) / kRsThreads;  // digits owned by one thread (blocked)
     __shared__ uint32_t wtab[kRsWaves][BINS];  // per wave: digit count, then next output slot
     __shared__ uint32_t wsum[kRsWaves];
     const uint32_t n = *n_ptr;
@@ -94,9 +105,18 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__res
 
     for (int k = threadIdx.x; k < kRsWaves * BINS; k += kRsThreads) (&wtab[0][0])[k] = 0;
     __syncthreads();
-    for (uint32_t j = 0; j < items; ++j) {
-        const uint32_t i = wbase + j * kWave + lane;
-        if (i < n) atomicAdd(&wtab[w][(keys_in[i] >> shift) & (BINS - 1)], 1u);
+    for (uint32_t j0 = 0; j0 < items; j0 += kRsBatch) {
+        uint32_t kk[kRsBatch];
+#pragma unroll
+        for (int u = 0; u < kRsBatch; ++u) {
+            const uint32_t i = wbase + (j0 + u) * kWave + lane;
+            kk[u] = (i < n) ? keys_in[i] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < kRsBatch; ++u) {
+            const uint32_t i = wbase + (j0 + u) * kWave + lane;
+            if (i < n) atomicAdd(&wtab[w][(kk[u] >> shift) & (BINS - 1)], 1u);
+        }
     }
     // ---- start of this block's span for every digit: exclusive scan of the digit
     //      totals + histogram rows of the blocks before this one
@@ -104,14 +124,28 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__res
     uint32_t tsum = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        tot[k] = totals[threadIdx.x * PER + k];  // thread t owns digits [t*PER, t*PER+PER)
+        const int dig = threadIdx.x * PER + k;  // thread t owns digits [t*PER, t*PER+PER)
+        tot[k] = dig < BINS ? totals[dig] : 0u;
         tsum += tot[k];
         before[k] = 0;
     }
-    for (uint32_t b = 0; b < blockIdx.x; ++b) {
-        const uint32_t *row = hist + (size_t)b * BINS + threadIdx.x * PER;
+    if (threadIdx.x * PER < BINS) {
+        const uint32_t *col = hist + threadIdx.x * PER;
+        uint32_t b = 0;
+        for (; b + 8 <= blockIdx.x; b += 8) {  // 8 rows in flight per step
+            uint32_t r[8][PER];
 #pragma unroll
-        for (int k = 0; k < PER; ++k) before[k] += row[k];
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int k = 0; k < PER; ++k) r[u][k] = col[(size_t)(b + u) * BINS + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int k = 0; k < PER; ++k) before[k] += r[u][k];
+        }
+        for (; b < blockIdx.x; ++b)
+#pragma unroll
+            for (int k = 0; k < PER; ++k) before[k] += col[(size_t)b * BINS + k];
     }
     const uint32_t inc = wave_inclusive_scan(tsum);
     if (lane == kWave - 1) wsum[w] = inc;
@@ -122,43 +156,55 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__res
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int dig = threadIdx.x * PER + k;
-        uint32_t slot = run + before[k];
+        if (dig < BINS) {
+            uint32_t slot = run + before[k];
 #pragma unroll
-        for (int ww = 0; ww < kRsWaves; ++ww) {  // counts -> first output slot of each wave
-            const uint32_t c = wtab[ww][dig];
-            wtab[ww][dig] = slot;
-            slot += c;
+            for (int ww = 0; ww < kRsWaves; ++ww) {  // counts -> first output slot of each wave
+                const uint32_t c = wtab[ww][dig];
+                wtab[ww][dig] = slot;
+                slot += c;
+            }
         }
         run += tot[k];
     }
     __syncthreads();
 
-    for (uint32_t j = 0; j < items; ++j) {
-        const uint32_t i = wbase + j * kWave + lane;
-        const bool valid = i < n;
-        const uint32_t key = valid ? keys_in[i] : 0xFFFFFFFFu;
-        const uint32_t d = (key >> shift) & (BINS - 1);
-        // lanes of this wave holding the same digit
-        uint64_t peers = __ballot(valid);
-        if (peers == 0) break;  // wave-uniform: the rest of the chunk is past the end
+    for (uint32_t j0 = 0; j0 < items; j0 += kRsBatch) {
+        if (wbase + j0 * kWave >= n) break;  // wave-uniform: the rest of the chunk is past the end
+        uint32_t kk[kRsBatch], vv[kRsBatch];
 #pragma unroll
-        for (int b = 0; b < BITS; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
+        for (int u = 0; u < kRsBatch; ++u) {
+            const uint32_t i = wbase + (j0 + u) * kWave + lane;
+            kk[u] = (i < n) ? keys_in[i] : 0xFFFFFFFFu;
+            vv[u] = (i < n && vals_in) ? vals_in[i] : i;
         }
-        const uint32_t rank = (uint32_t)__popcll(peers & lanemask_lt());
-        uint32_t slot = 0;
-        if (valid && rank == 0) {  // lowest lane of each digit group claims the group's slots
-            slot = wtab[w][d];
-            wtab[w][d] = slot + (uint32_t)__popcll(peers);
-        }
-        wave_lds_fence();
-        slot = __shfl(slot, valid ? (int)__builtin_ctzll(peers) : lane, kWave);
-        if (valid) {
-            const uint32_t dst = slot + rank;
-            keys_out[dst] = key;
-            vals_out[dst] = vals_in ? vals_in[i] : i;
+#pragma unroll
+        for (int u = 0; u < kRsBatch; ++u) {
+            const uint32_t i = wbase + (j0 + u) * kWave + lane;
+            const bool valid = i < n;
+            const uint32_t key = kk[u];
+            const uint32_t d = (key >> shift) & (BINS - 1);
+            // lanes of this wave holding the same digit
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < BITS; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
+            const uint32_t rank = (uint32_t)__popcll(peers & lanemask_lt());
+            uint32_t slot = 0;
+            if (valid && rank == 0) {  // lowest lane of each digit group claims the group's slots
+                slot = wtab[w][d];
+                wtab[w][d] = slot + (uint32_t)__popcll(peers);
+            }
+            wave_lds_fence();
+            slot = __shfl(slot, valid ? (int)__builtin_ctzll(peers) : lane, kWave);
+            if (valid) {
+                const uint32_t dst = slot + rank;
+                keys_out[dst] = key;
+                vals_out[dst] = vv[u];
+            }
         }
     }
 }
