@@ -139,10 +139,11 @@ def load():
         "gm_nearest": (C.c_int, [vp, fp, u32, fp, u32, i32p]),
         "gm_solve_local_frame": (C.c_int, [dp, fp, fp]),
         "gm_set_owned_range": (C.c_int, [vp, C.c_double, C.c_double]),
-        "gm_score_planes": (C.c_int, [vp, fp, u32, fp, u32, C.c_double, i32p]),
-        "gm_score_cylinders": (C.c_int, [vp, fp, u32, fp, u32, C.c_double, i32p]),
-        "gm_plane_hypotheses": (C.c_int, [vp, fp, u32, C.c_uint64, u32, fp]),
-        "gm_cylinder_hypotheses": (C.c_int, [vp, fp, fp, u32, C.c_uint64, u32, fp]),
+        "gm_ext_available": (C.c_int, []),
+        "gm_score_planes": (C.c_int, [vp, fp, u32, u8p, u32, fp, u32, C.c_double, i32p]),
+        "gm_score_cylinders": (C.c_int, [vp, fp, u32, u8p, u32, fp, u32, C.c_double, i32p]),
+        "gm_plane_hypotheses": (C.c_int, [vp, fp, u32, u8p, u32, C.c_uint64, u32, fp]),
+        "gm_cylinder_hypotheses": (C.c_int, [vp, fp, fp, u32, u8p, u32, C.c_uint64, u32, fp]),
         "gm_segment_moments": (C.c_int, [vp, fp, fp, u8p, u32, u32, dp]),
         "gm_get_compressed_map": (C.c_int, [vp, u32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     }

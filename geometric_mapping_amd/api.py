@@ -19,7 +19,7 @@ from . import _lib
 from ._lib import (GM_CFG_DEFAULT, GM_CFG_KEEP_COUNTS, GM_CFG_STAGE_TIMING, GM_CFG_VOXEL_GRID, GM_CLOUD_BIGENDIAN,
                    GM_CLOUD_DEVICE, GM_ERR_CAPACITY, GM_OK, Cloud, Config, FrameResult, GmError, STAGE_NAMES)
 
-__all__ = ["GeometricMapping", "GmError", "solve_local_frame"]
+__all__ = ["GeometricMapping", "GmError", "solve_local_frame", "decode_compressed_map"]
 
 
 def _f32(a):
@@ -166,6 +166,24 @@ class GeometricMapping:
     def neighbor_counts(self, slot=0):
         return self._fetch(self._L.gm_get_neighbor_counts, slot, 1, np.int32)
 
+    def voxel_nearest(self, slot=0):
+        """Index (into cropped_cloud()) of the nearest point of every voxel centroid (GM_CFG_NEAREST)."""
+        return self._fetch(self._L.gm_get_voxel_nearest, slot, 1, np.int32)
+
+    def labels(self, slot=0):
+        """Extension: segment label per valid point (0 none, 1 plane, 2 cylinder)."""
+        return self._fetch(self._L.gm_get_labels, slot, 1, np.uint8)
+
+    def compressed_map(self, slot=0):
+        """Extension: raw bytes of the build-defined map record (see decode_compressed_map)."""
+        n = C.c_size_t(0)
+        st = self._L.gm_get_compressed_map(self._ctx, slot, None, 0, C.byref(n))
+        if st not in (GM_OK, GM_ERR_CAPACITY):
+            self._check(st)
+        buf = np.zeros(n.value, dtype=np.uint8)
+        self._check(self._L.gm_get_compressed_map(self._ctx, slot, buf.ctypes.data, n.value, C.byref(n)))
+        return buf
+
     def set_owned_range(self, lo, hi):
         self._check(self._L.gm_set_owned_range(self._ctx, float(lo), float(hi)))
 
@@ -225,6 +243,84 @@ class GeometricMapping:
                                           C.byref(n), C.byref(fl)))
         out = out[:n.value]
         return out[:, :3].copy(), out[:, 3].astype(np.int32), bool(fl.value & _lib.GM_RES_VOXEL_PASSTHROUGH)
+
+
+    # ---- extensions (no reference counterpart; SURVEY.md par. 8a-ext) ----
+    @staticmethod
+    def _u8(a):
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        return a, a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+    def nearest(self, cloud, queries):
+        xyz = np.ascontiguousarray(cloud, dtype=np.float32)
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        idx = np.empty(max(len(q), 1), dtype=np.int32)
+        self._check(self._L.gm_nearest(self._ctx, _f32(xyz), len(xyz), _f32(q), len(q),
+                                       idx.ctypes.data_as(C.POINTER(C.c_int32))))
+        return idx[:len(q)].copy()
+
+    def plane_hypotheses(self, cloud, seed, H, labels=None, want=0):
+        xyz = np.ascontiguousarray(cloud, dtype=np.float32)
+        lab, lp = self._u8(labels)
+        out = np.empty((H, 4), dtype=np.float32)
+        self._check(self._L.gm_plane_hypotheses(self._ctx, _f32(xyz), len(xyz), lp, want, seed, H, _f32(out)))
+        return out
+
+    def cylinder_hypotheses(self, cloud, normals, seed, H, labels=None, want=0):
+        xyz = np.ascontiguousarray(cloud, dtype=np.float32)
+        nrm = np.ascontiguousarray(normals, dtype=np.float32)
+        lab, lp = self._u8(labels)
+        out = np.empty((H, 7), dtype=np.float32)
+        self._check(self._L.gm_cylinder_hypotheses(self._ctx, _f32(xyz), _f32(nrm), len(xyz), lp, want, seed, H, _f32(out)))
+        return out
+
+    def _score(self, fn, cloud, hyp, tau, labels, want):
+        xyz = np.ascontiguousarray(cloud, dtype=np.float32)
+        hyp = np.ascontiguousarray(hyp, dtype=np.float32)
+        lab, lp = self._u8(labels)
+        cnt = np.zeros(len(hyp), dtype=np.int32)
+        self._check(fn(self._ctx, _f32(xyz), len(xyz), lp, want, _f32(hyp), len(hyp), float(tau),
+                       cnt.ctypes.data_as(C.POINTER(C.c_int32))))
+        return cnt
+
+    def score_planes(self, cloud, hyp4, tau, labels=None, want=0):
+        return self._score(self._L.gm_score_planes, cloud, hyp4, tau, labels, want)
+
+    def score_cylinders(self, cloud, hyp7, tau, labels=None, want=0):
+        return self._score(self._L.gm_score_cylinders, cloud, hyp7, tau, labels, want)
+
+    def segment_moments(self, cloud, normals, labels, label):
+        xyz = np.ascontiguousarray(cloud, dtype=np.float32)
+        nrm = np.ascontiguousarray(normals, dtype=np.float32) if normals is not None else None
+        lab, lp = self._u8(labels)
+        mom = np.zeros(16, dtype=np.float64)
+        self._check(self._L.gm_segment_moments(self._ctx, _f32(xyz), _f32(nrm) if nrm is not None else None, lp,
+                                               len(xyz), label, mom.ctypes.data_as(C.POINTER(C.c_double))))
+        return mom
+
+
+def decode_compressed_map(buf):
+    """Parse gm_get_compressed_map bytes (gm_map_header / gm_map_primitive in include/gm_hip.h)."""
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    if bytes(buf[:4]) != b"GMAP":
+        raise ValueError("not a GMAP record")
+    version, nprim, nvox = np.frombuffer(buf, np.uint32, 3, 4)
+    leaf, bound = np.frombuffer(buf, np.float32, 2, 16)
+    n_points = int(np.frombuffer(buf, np.uint32, 1, 24)[0])
+    ev = np.frombuffer(buf, np.float32, 3, 32).copy()
+    axis = np.frombuffer(buf, np.float32, 3, 44).copy()
+    off = 56
+    prims = []
+    for _ in range(int(nprim)):
+        typ, inl = np.frombuffer(buf, np.uint32, 2, off)
+        params = np.frombuffer(buf, np.float32, 7, off + 8).copy()
+        prims.append(dict(type=int(typ), inliers=int(inl), params=params))
+        off += 40
+    vox = np.frombuffer(buf, np.float32, 4 * int(nvox), off).reshape(-1, 4).copy()
+    return dict(version=int(version), leaf=float(leaf), bound=float(bound), n_points=n_points, eigenvalues=ev,
+                center_axis=axis, primitives=prims, voxels=vox)
 
 
 def solve_local_frame(scatter6):

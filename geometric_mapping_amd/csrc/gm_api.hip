@@ -184,6 +184,10 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud)
     if (n && !cloud->data) return fail(ctx, GM_ERR_INVALID_ARG, "gm_cloud.data is NULL");
     gm_status st = ensure_capacity(ctx, sl, n, raw_bytes, !on_dev);
     if (st != GM_OK) return st;
+    if (ctx->cfg.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER | GM_CFG_NEAREST)) {
+        st = gm_ensure_ext(ctx, sl, ctx->cfg.ransac_hypotheses ? ctx->cfg.ransac_hypotheses : 1);
+        if (st != GM_OK) return st;
+    }
     hipStream_t s = sl.stream;
     sl.n_in = n;
     st = reset_counters(ctx, sl);
@@ -238,9 +242,19 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud)
         }
     }
     record(ctx, sl, 6);
+    if (cf.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)) {
+        st = gm_enqueue_ransac(ctx, sl, n);
+        if (st != GM_OK) return st;
+    }
+    if ((cf.flags & GM_CFG_NEAREST) && (cf.flags & GM_CFG_VOXEL_GRID)) {
+        const uint32_t nq_cap = vd.enabled ? (uint32_t)vd.dim * vd.dim * vd.dim : n;
+        launch_nearest(sl.valid4, &sl.ctr->n_valid, n, sl.vox4, &sl.ctr->n_voxels, nq_cap < n ? nq_cap : n, sl.nn_best,
+                       sl.vox_nn, s);
+    }
+    record(ctx, sl, 7);
     launch_frame_finalize(nparts, sl, s);
     GM_HIP(ctx, hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(FrameOut), hipMemcpyDeviceToHost, s));
-    record(ctx, sl, 7);
+    record(ctx, sl, 8);
     GM_HIP(ctx, hipGetLastError());
     sl.submitted = true;
     sl.complete = false;
@@ -260,14 +274,21 @@ void fill_result(gm_ctx *ctx, Slot &sl, gm_frame_result *r)
     for (int k = 0; k < 3; ++k) r->center_axis[k] = o.evecs[k];  // block<3,1>(0,0)
     for (int k = 0; k < 6; ++k) r->scatter[k] = o.scatter[k];
     if ((ctx->cfg.flags & GM_CFG_VOXEL_GRID) && o.vox.passthrough) r->status_flags |= GM_RES_VOXEL_PASSTHROUGH;
+    if (ctx->cfg.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)) {
+        r->plane_inliers = o.ext.plane_inliers;
+        r->cylinder_inliers = o.ext.cylinder_inliers;
+        for (int k = 0; k < 4; ++k) { r->plane[k] = o.ext.plane[k]; r->plane_refit[k] = o.ext.plane_refit[k]; }
+        for (int k = 0; k < 7; ++k) r->cylinder[k] = o.ext.cylinder[k];
+        for (int k = 0; k < 3; ++k) r->cylinder_axis_refit[k] = o.ext.cyl_axis_refit[k];
+    }
     float ms = 0;
     if (sl.n_in && hipEventElapsedTime(&ms, sl.ev_k0, sl.ev_k1) == hipSuccess) r->normals_kernel_ms = ms;
     if (ctx->cfg.flags & GM_CFG_STAGE_TIMING) {
-        static const int stage_of[7] = {GM_STAGE_UPLOAD, GM_STAGE_CROP, GM_STAGE_NORMALS, GM_STAGE_COMPACT,
-                                        GM_STAGE_FRAME, GM_STAGE_VOXEL, GM_STAGE_FRAME};
-        for (int i = 0; i < 7; ++i)
+        static const int stage_of[8] = {GM_STAGE_UPLOAD, GM_STAGE_CROP, GM_STAGE_NORMALS, GM_STAGE_COMPACT,
+                                        GM_STAGE_FRAME, GM_STAGE_VOXEL, GM_STAGE_RANSAC, GM_STAGE_FRAME};
+        for (int i = 0; i < 8; ++i)
             if (hipEventElapsedTime(&ms, sl.ev[i], sl.ev[i + 1]) == hipSuccess) r->stage_ms[stage_of[i]] += ms;
-        if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[7]) == hipSuccess) r->stage_ms[GM_STAGE_TOTAL] = ms;
+        if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[8]) == hipSuccess) r->stage_ms[GM_STAGE_TOTAL] = ms;
         r->stage_ms[GM_STAGE_GRID] = r->stage_ms[GM_STAGE_NORMALS] - r->normals_kernel_ms;
         r->stage_ms[GM_STAGE_NORMALS] = r->normals_kernel_ms;
     }
@@ -319,6 +340,76 @@ gm_status begin_stage(gm_ctx *ctx, Slot *&sl)
 }
 
 }  // namespace
+
+namespace gm {
+
+gm_status gm_fail(gm_ctx *ctx, gm_status st, const char *msg) { return fail(ctx, st, msg); }
+gm_status gm_ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, bool need_raw)
+{
+    return ensure_capacity(ctx, sl, n, raw_bytes, need_raw);
+}
+gm_status gm_begin_stage(gm_ctx *ctx, Slot *&sl) { return begin_stage(ctx, sl); }
+gm_status gm_check_slot(gm_ctx *ctx, uint32_t slot) { return check_slot(ctx, slot); }
+
+gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H)
+{
+    if (H == 0 || H > kMaxHypotheses) return fail(ctx, GM_ERR_INVALID_ARG, "ransac_hypotheses must be in [1, 8192]");
+    if (H <= sl.ext_H && sl.cap <= sl.ext_cap) return GM_OK;
+    GM_HIP(ctx, hipStreamSynchronize(sl.stream));
+    hipFree(sl.hyp_plane); hipFree(sl.hyp_cyl); hipFree(sl.band); hipFree(sl.score_partial); hipFree(sl.cnt_plane);
+    hipFree(sl.cnt_cyl); hipFree(sl.best_plane); hipFree(sl.best_cyl); hipFree(sl.mom_partial); hipFree(sl.mom_plane);
+    hipFree(sl.mom_cyl); hipFree(sl.nn_best);
+    sl.ext_H = 0; sl.ext_cap = 0;
+    const uint32_t HH = H > sl.ext_H ? H : sl.ext_H;
+    GM_HIP(ctx, dmalloc(sl.hyp_plane, (size_t)HH * 8)); GM_HIP(ctx, dmalloc(sl.hyp_cyl, (size_t)HH * 8));
+    GM_HIP(ctx, dmalloc(sl.band, HH));
+    GM_HIP(ctx, dmalloc(sl.score_partial, (size_t)(score_blocks(sl.cap) + 1) * HH));
+    GM_HIP(ctx, dmalloc(sl.cnt_plane, HH)); GM_HIP(ctx, dmalloc(sl.cnt_cyl, HH));
+    GM_HIP(ctx, dmalloc(sl.best_plane, 2)); GM_HIP(ctx, dmalloc(sl.best_cyl, 2));
+    GM_HIP(ctx, dmalloc(sl.mom_partial, (size_t)kScatterBlocks * 16));
+    GM_HIP(ctx, dmalloc(sl.mom_plane, 16)); GM_HIP(ctx, dmalloc(sl.mom_cyl, 16));
+    GM_HIP(ctx, dmalloc(sl.nn_best, sl.cap));
+    GM_HIP(ctx, hipMemset(sl.best_plane, 0xFF, 8));
+    GM_HIP(ctx, hipMemset(sl.best_cyl, 0xFF, 8));
+    sl.ext_H = HH; sl.ext_cap = sl.cap;
+    return GM_OK;
+}
+
+// sequential multi-model RANSAC over the valid cloud of a frame: plane first (label 1),
+// then cylinder on what is left (label 2), moments + refits per segment
+gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap)
+{
+    const gm_config &cf = ctx->cfg;
+    const bool do_plane = (cf.flags & GM_CFG_RANSAC_PLANE) != 0, do_cyl = (cf.flags & GM_CFG_RANSAC_CYLINDER) != 0;
+    if (!do_plane && !do_cyl) return GM_OK;
+    const uint32_t H = cf.ransac_hypotheses;
+    hipStream_t s = sl.stream;
+    const uint32_t *n_ptr = &sl.ctr->n_valid;
+    GM_HIP(ctx, hipMemsetAsync(sl.labels, 0, n_cap ? n_cap : 1, s));
+    GM_HIP(ctx, hipMemsetAsync(sl.best_plane, 0xFF, 8, s));
+    GM_HIP(ctx, hipMemsetAsync(sl.best_cyl, 0xFF, 8, s));
+    if (do_plane) {
+        launch_plane_hypotheses(sl.valid4, sl.labels, 0, n_ptr, n_cap, cf.ransac_seed, H, sl.hyp_plane, s);
+        launch_score(0, sl.valid4, sl.labels, 0, n_ptr, n_cap, sl.hyp_plane, sl.band, H, cf.ransac_threshold,
+                     sl.score_partial, sl.cnt_plane, sl.best_plane, s);
+        launch_label(0, sl.valid4, sl.labels, 0, 1, n_ptr, n_cap, sl.hyp_plane, sl.band, sl.best_plane,
+                     cf.ransac_threshold, s);
+        launch_segment_moments(sl.valid4, sl.vnorm4, sl.labels, 1, n_ptr, n_cap, sl.mom_partial, sl.mom_plane, s);
+    }
+    if (do_cyl) {
+        launch_cylinder_hypotheses(sl.valid4, sl.vnorm4, sl.labels, 0, n_ptr, n_cap, cf.ransac_seed + 1, H, sl.hyp_cyl, s);
+        launch_score(1, sl.valid4, sl.labels, 0, n_ptr, n_cap, sl.hyp_cyl, sl.band, H, cf.ransac_threshold,
+                     sl.score_partial, sl.cnt_cyl, sl.best_cyl, s);
+        launch_label(1, sl.valid4, sl.labels, 0, 2, n_ptr, n_cap, sl.hyp_cyl, sl.band, sl.best_cyl,
+                     cf.ransac_threshold, s);
+        launch_segment_moments(sl.valid4, sl.vnorm4, sl.labels, 2, n_ptr, n_cap, sl.mom_partial, sl.mom_cyl, s);
+    }
+    launch_ext_finalize(sl.hyp_plane, do_plane ? sl.best_plane : nullptr, sl.hyp_cyl, do_cyl ? sl.best_cyl : nullptr,
+                        sl.mom_plane, sl.mom_cyl, &sl.d_out->ext, s);
+    return GM_OK;
+}
+
+}  // namespace gm
 
 extern "C" {
 
@@ -432,7 +523,9 @@ void gm_destroy(gm_ctx *ctx)
             if (sl.stream) hipStreamSynchronize(sl.stream);
             free_slot_buffers(sl);
             hipFree(sl.ctr); hipFree(sl.voxp); hipFree(sl.d_out); hipFree(sl.partials); hipFree(sl.vox_table);
-            hipFree(sl.hyp); hipFree(sl.hyp_counts); hipFree(sl.seg_mom);
+            hipFree(sl.hyp_plane); hipFree(sl.hyp_cyl); hipFree(sl.band); hipFree(sl.score_partial);
+            hipFree(sl.cnt_plane); hipFree(sl.cnt_cyl); hipFree(sl.best_plane); hipFree(sl.best_cyl);
+            hipFree(sl.mom_partial); hipFree(sl.mom_plane); hipFree(sl.mom_cyl); hipFree(sl.nn_best);
             if (sl.h_out) hipHostFree(sl.h_out);
             for (int k = 0; k <= GM_N_STAGES; ++k) if (sl.ev[k]) hipEventDestroy(sl.ev[k]);
             if (sl.ev_k0) hipEventDestroy(sl.ev_k0);

@@ -61,12 +61,23 @@ struct VoxDense {
     double scale, inv_scale;
 };
 
+// extension outputs (RANSAC plane / cylinder; no reference counterpart)
+struct FrameExt {
+    float plane[4];
+    float cylinder[7];
+    uint32_t plane_inliers, cylinder_inliers;
+    uint32_t pad;
+    double plane_refit[4];
+    double cyl_axis_refit[3];
+};
+
 struct FrameOut {        // device -> host result record (one small D2H per frame)
     DevCounters ctr;
     float evals[3];
     float evecs[9];      // column-major
     double scatter[6];
     VoxelParams vox;
+    FrameExt ext;
 };
 
 // ---- wave-level primitives ---------------------------------------------------

@@ -59,10 +59,16 @@ struct Slot {
     VoxelParams *voxp = nullptr;
     FrameOut *d_out = nullptr;
     FrameOut *h_out = nullptr;    // pinned
-    // extension scratch
-    float *hyp = nullptr;         // [H][8]
-    int32_t *hyp_counts = nullptr;
-    double *seg_mom = nullptr;
+    // extension scratch (allocated on first use)
+    uint32_t ext_H = 0, ext_cap = 0;
+    float *hyp_plane = nullptr, *hyp_cyl = nullptr;   // [H][8]
+    float2 *band = nullptr;                           // [H]
+    uint32_t *score_partial = nullptr;                // [score_blocks][H]
+    int32_t *cnt_plane = nullptr, *cnt_cyl = nullptr; // [H]
+    uint32_t *best_plane = nullptr, *best_cyl = nullptr; // [2]
+    double *mom_partial = nullptr;                    // [kScatterBlocks][16]
+    double *mom_plane = nullptr, *mom_cyl = nullptr;  // [16]
+    unsigned long long *nn_best = nullptr;            // [cap]
     // state
     bool submitted = false, complete = false;
     uint32_t n_in = 0;
@@ -109,6 +115,36 @@ void launch_frame_finalize(uint32_t n_partials, Slot &sl, hipStream_t s);
 void launch_voxel_grid(Slot &sl, uint32_t n_cap, float leaf, int key_bits, hipStream_t s);
 void launch_voxel_dense_finalize(const VoxDense &vd, Slot &sl, hipStream_t s);
 constexpr uint32_t kVoxDenseMaxCells = 1u << 18;
+// k_ransac.hip (extensions)
+constexpr uint32_t kMaxHypotheses = 8192;
+uint32_t score_blocks(uint32_t n_cap);
+void launch_plane_hypotheses(const float4 *pts, const uint8_t *labels, uint32_t want, const uint32_t *n_ptr,
+                             uint32_t n_host, uint64_t seed, uint32_t H, float *hyp8, hipStream_t s);
+void launch_cylinder_hypotheses(const float4 *pts, const float4 *nrm, const uint8_t *labels, uint32_t want,
+                                const uint32_t *n_ptr, uint32_t n_host, uint64_t seed, uint32_t H, float *hyp8,
+                                hipStream_t s);
+void launch_score(int model, const float4 *pts, const uint8_t *labels, uint32_t want, const uint32_t *n_ptr,
+                  uint32_t n_cap, const float *hyp8, float2 *band, uint32_t H, double tau, uint32_t *partial,
+                  int32_t *counts, uint32_t *best, hipStream_t s);
+void launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, uint32_t label, const uint32_t *n_ptr,
+                  uint32_t n_cap, const float *hyp8, const float2 *band, const uint32_t *best, double tau,
+                  hipStream_t s);
+void launch_segment_moments(const float4 *pts, const float4 *nrm, const uint8_t *labels, uint32_t label,
+                            const uint32_t *n_ptr, uint32_t n_cap, double *partial, double *mom16, hipStream_t s);
+void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, const float *hyp_cyl,
+                         const uint32_t *best_cyl, const double *mom_plane, const double *mom_cyl, FrameExt *ext,
+                         hipStream_t s);
+// k_nearest.hip
+void launch_nearest(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, const float4 *queries,
+                    const uint32_t *nq_ptr, uint32_t nq_cap, unsigned long long *best, int32_t *idx, hipStream_t s);
+
+// gm_api.hip helpers shared with gm_ext.hip
+gm_status gm_fail(gm_ctx *ctx, gm_status st, const char *msg);
+gm_status gm_ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, bool need_raw);
+gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H);
+gm_status gm_begin_stage(gm_ctx *ctx, Slot *&sl);
+gm_status gm_check_slot(gm_ctx *ctx, uint32_t slot);
+gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap);
 void launch_minmax(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, DevCounters *ctr, hipStream_t s);
 
 }  // namespace gm

@@ -1,0 +1,425 @@
+// k_ransac.hip -- BUILD-DEFINED EXTENSIONS: batched RANSAC plane / cylinder
+// hypothesis scoring, inlier labelling, per-segment moment accumulation, refits.
+//
+// The reference has NO counterpart: getCylinder is an empty commented stub
+// (/root/reference src/tunnel_processing.cpp:149-154, tunnel_processing.hpp:56-59),
+// its publisher and parameter are commented out (src/geometric_mapping.cpp:41,
+// 119-122,163-166).  Conventions follow PCL's SampleConsensusModelPlane /
+// SampleConsensusModelCylinder (SURVEY.md par. 8a-ext); the CPU restatement is
+// oracle/gm_oracle_ext.c.  Parity for everything here is "vs the build's own
+// restatement + analytic truth", never "vs reference".
+//
+// Scoring kernel shape (HBM-streaming in points, compute-bound in H):
+//   lane <-> point (8 points per lane held in registers, loaded once, coalesced 16 B),
+//   hypotheses are wave-uniform: they arrive through scalar loads (SGPR operands),
+//   an inlier test is 3 v_fma + 1 v_cmp whose result IS the wave ballot (SGPR pair),
+//   s_bcnt1 counts it; per-block sums go through LDS, per-block rows to HBM with plain
+//   stores, and a second kernel sums the rows in fixed order and picks the arg-max.
+//   No float atomics anywhere: counts are integers, results are run-to-run identical.
+#include "gm_internal.hpp"
+
+namespace gm {
+
+constexpr int kScThreads = 256;
+constexpr int kScP = 8;                       // points per lane
+constexpr int kScTile = kScThreads * kScP;    // points per block
+constexpr int kMaxDraws = 64;
+
+__host__ __device__ inline uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ inline uint32_t draw_index(uint64_t seed, uint32_t h, uint32_t t, uint32_t n)
+{
+    const uint64_t u = mix64(seed ^ mix64(((uint64_t)h << 8) | t));
+    return (uint32_t)(((u >> 32) * (uint64_t)n) >> 32);
+}
+
+__device__ inline uint32_t next_sample(uint64_t seed, uint32_t h, uint32_t &t, uint32_t n,
+                                       const uint8_t *__restrict__ labels, uint32_t want, uint32_t a, uint32_t b)
+{
+    while (t < (uint32_t)kMaxDraws) {
+        const uint32_t i = draw_index(seed, h, t++, n);
+        if (i == a || i == b) continue;
+        if (labels && labels[i] != want) continue;
+        return i;
+    }
+    return 0xFFFFFFFFu;
+}
+
+__device__ inline void store_nan(float *o, int k)
+{
+    for (int i = 0; i < k; ++i) o[i] = __builtin_nanf("");
+}
+
+// hyp8 rows: plane a,b,c,d,-,-,-,-   cylinder px,py,pz,dx,dy,dz,r,-
+__global__ __launch_bounds__(256) void k_plane_hypotheses(const float4 *__restrict__ pts,
+                                                          const uint8_t *__restrict__ labels, uint32_t want,
+                                                          const uint32_t *__restrict__ n_ptr, uint32_t n_host,
+                                                          uint64_t seed, uint32_t H, float *__restrict__ hyp8)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    float *o = hyp8 + 8 * (size_t)h;
+    for (int k = 4; k < 8; ++k) o[k] = 0.f;
+    if (n < 3) { store_nan(o, 4); return; }
+    uint32_t t = 0;
+    const uint32_t none = 0xFFFFFFFFu;
+    const uint32_t i0 = next_sample(seed, h, t, n, labels, want, none, none);
+    const uint32_t i1 = i0 == none ? none : next_sample(seed, h, t, n, labels, want, i0, none);
+    const uint32_t i2 = i1 == none ? none : next_sample(seed, h, t, n, labels, want, i0, i1);
+    if (i2 == none) { store_nan(o, 4); return; }
+    const float4 p0 = pts[i0], p1 = pts[i1], p2 = pts[i2];
+    const double ax = (double)p1.x - p0.x, ay = (double)p1.y - p0.y, az = (double)p1.z - p0.z;
+    const double bx = (double)p2.x - p0.x, by = (double)p2.y - p0.y, bz = (double)p2.z - p0.z;
+    double nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    const double len = sqrt(nx * nx + ny * ny + nz * nz);
+    if (!(len > 1e-12)) { store_nan(o, 4); return; }
+    nx /= len; ny /= len; nz /= len;
+    const double d = -(nx * p0.x + ny * p0.y + nz * p0.z);
+    o[0] = (float)nx; o[1] = (float)ny; o[2] = (float)nz; o[3] = (float)d;
+}
+
+__global__ __launch_bounds__(256) void k_cylinder_hypotheses(const float4 *__restrict__ pts,
+                                                             const float4 *__restrict__ nrm,
+                                                             const uint8_t *__restrict__ labels, uint32_t want,
+                                                             const uint32_t *__restrict__ n_ptr, uint32_t n_host,
+                                                             uint64_t seed, uint32_t H, float *__restrict__ hyp8)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    float *o = hyp8 + 8 * (size_t)h;
+    o[7] = 0.f;
+    if (n < 2) { store_nan(o, 7); return; }
+    uint32_t t = 0;
+    const uint32_t none = 0xFFFFFFFFu;
+    const uint32_t i0 = next_sample(seed, h, t, n, labels, want, none, none);
+    const uint32_t i1 = i0 == none ? none : next_sample(seed, h, t, n, labels, want, i0, none);
+    if (i1 == none) { store_nan(o, 7); return; }
+    const float4 P1 = pts[i0], P2 = pts[i1], N1 = nrm[i0], N2 = nrm[i1];
+    const double p1[3] = {P1.x, P1.y, P1.z}, p2[3] = {P2.x, P2.y, P2.z};
+    const double n1[3] = {N1.x, N1.y, N1.z}, n2[3] = {N2.x, N2.y, N2.z};
+    // closest points of the two normal lines (p1+n1)+s*n1 and p2+t*n2
+    const double w[3] = {n1[0] + p1[0] - p2[0], n1[1] + p1[1] - p2[1], n1[2] + p1[2] - p2[2]};
+    const double a = n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2];
+    const double b = n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2];
+    const double c = n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2];
+    const double d = n1[0] * w[0] + n1[1] * w[1] + n1[2] * w[2];
+    const double e = n2[0] * w[0] + n2[1] * w[1] + n2[2] * w[2];
+    const double den = a * c - b * b;
+    double sc, tc;
+    if (den < 1e-8) { sc = 0.0; tc = (b > c ? d / b : e / c); }
+    else { sc = (b * e - c * d) / den; tc = (a * e - b * d) / den; }
+    double lp[3], ld[3];
+    for (int k = 0; k < 3; ++k) lp[k] = p1[k] + n1[k] + sc * n1[k];
+    for (int k = 0; k < 3; ++k) ld[k] = p2[k] + tc * n2[k] - lp[k];
+    const double len = sqrt(ld[0] * ld[0] + ld[1] * ld[1] + ld[2] * ld[2]);
+    if (!(len > 1e-9) || !isfinite(len)) { store_nan(o, 7); return; }
+    for (int k = 0; k < 3; ++k) ld[k] /= len;
+    const double v[3] = {p1[0] - lp[0], p1[1] - lp[1], p1[2] - lp[2]};
+    const double tt = v[0] * ld[0] + v[1] * ld[1] + v[2] * ld[2];
+    const double q = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] - tt * tt;
+    const double r = sqrt(q > 0 ? q : 0);
+    o[0] = (float)lp[0]; o[1] = (float)lp[1]; o[2] = (float)lp[2];
+    o[3] = (float)ld[0]; o[4] = (float)ld[1]; o[5] = (float)ld[2];
+    o[6] = (float)r;
+}
+
+// inlier band of a cylinder hypothesis: (r-tau)^2 < dist_axis^2 < (r+tau)^2, both ends in fp32
+__host__ __device__ inline void cyl_band(float r, double tau, float &lo2, float &hi2)
+{
+    const double lo = (double)r - tau, hi = (double)r + tau;
+    lo2 = lo > 0 ? (float)(lo * lo) : -1.0f;
+    hi2 = (float)(hi * hi);
+}
+
+__global__ __launch_bounds__(256) void k_cyl_bands(const float *__restrict__ hyp8, uint32_t H, double tau,
+                                                   float2 *__restrict__ band)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    float lo2, hi2;
+    cyl_band(hyp8[8 * (size_t)h + 6], tau, lo2, hi2);
+    band[h] = make_float2(lo2, hi2);
+}
+
+__device__ __forceinline__ bool plane_inlier(float x, float y, float z, float a, float b, float c, float d, float tau)
+{
+    const float dist = __fmaf_rn(a, x, __fmaf_rn(b, y, __fmaf_rn(c, z, d)));
+    return fabsf(dist) < tau;  // NaN hypothesis or masked (NaN) point -> false
+}
+
+__device__ __forceinline__ bool cyl_inlier(float x, float y, float z, float px, float py, float pz, float dx, float dy,
+                                           float dz, float lo2, float hi2)
+{
+    const float vx = __fsub_rn(x, px), vy = __fsub_rn(y, py), vz = __fsub_rn(z, pz);
+    const float t = __fmaf_rn(vx, dx, __fmaf_rn(vy, dy, __fmul_rn(vz, dz)));
+    const float vv = __fmaf_rn(vx, vx, __fmaf_rn(vy, vy, __fmul_rn(vz, vz)));
+    const float q = __fmaf_rn(-t, t, vv);
+    return q > lo2 && q < hi2;
+}
+
+// MODEL 0: plane, 1: cylinder.  partial[blockIdx.x][h] = inliers of hypothesis h among this block's points.
+template <int MODEL>
+__global__ __launch_bounds__(kScThreads) void k_score(const float4 *__restrict__ pts,
+                                                      const uint8_t *__restrict__ labels, uint32_t want,
+                                                      const uint32_t *__restrict__ n_ptr, uint32_t n_host,
+                                                      const float *__restrict__ hyp8,
+                                                      const float2 *__restrict__ band, uint32_t H, float tau,
+                                                      uint32_t *__restrict__ partial)
+{
+    extern __shared__ uint32_t lcnt[];  // [H]
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    const uint32_t base = blockIdx.x * kScTile;
+    for (uint32_t h = threadIdx.x; h < H; h += kScThreads) lcnt[h] = 0;
+    __syncthreads();
+    if (base < n) {
+        float px[kScP], py[kScP], pz[kScP];
+#pragma unroll
+        for (int p = 0; p < kScP; ++p) {
+            const uint32_t i = base + p * kScThreads + threadIdx.x;
+            bool ok = i < n;
+            if (ok && labels) ok = labels[i] == want;
+            float4 v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 0.f);
+            if (ok) v = pts[i];
+            px[p] = v.x; py[p] = v.y; pz[p] = v.z;
+        }
+        for (uint32_t h = 0; h < H; ++h) {
+            const float *hy = hyp8 + 8 * (size_t)h;  // wave-uniform address: scalar loads
+            uint32_t c = 0;
+            if (MODEL == 0) {
+                const float a = hy[0], b = hy[1], cc = hy[2], d = hy[3];
+#pragma unroll
+                for (int p = 0; p < kScP; ++p)
+                    c += (uint32_t)__popcll(__ballot(plane_inlier(px[p], py[p], pz[p], a, b, cc, d, tau)));
+            } else {
+                const float qx = hy[0], qy = hy[1], qz = hy[2], dx = hy[3], dy = hy[4], dz = hy[5];
+                const float2 bd = band[h];
+#pragma unroll
+                for (int p = 0; p < kScP; ++p)
+                    c += (uint32_t)__popcll(__ballot(cyl_inlier(px[p], py[p], pz[p], qx, qy, qz, dx, dy, dz, bd.x, bd.y)));
+            }
+            if (lane_id() == 0 && c) atomicAdd(&lcnt[h], c);
+        }
+    }
+    __syncthreads();
+    for (uint32_t h = threadIdx.x; h < H; h += kScThreads) partial[(size_t)blockIdx.x * H + h] = lcnt[h];
+}
+
+// fixed-order column sums + arg-max (largest count, lowest index on ties)
+__global__ __launch_bounds__(1024) void k_best_hypothesis(const uint32_t *__restrict__ partial, uint32_t nblocks,
+                                                          uint32_t H, int32_t *__restrict__ counts,
+                                                          uint32_t *__restrict__ best /* [2]: index, count */)
+{
+    __shared__ uint32_t bc[1024], bi[1024];
+    uint32_t my_c = 0, my_i = 0xFFFFFFFFu;
+    for (uint32_t h = threadIdx.x; h < H; h += 1024) {
+        uint32_t s = 0;
+        for (uint32_t b = 0; b < nblocks; ++b) s += partial[(size_t)b * H + h];
+        counts[h] = (int32_t)s;
+        if (my_i == 0xFFFFFFFFu || s > my_c) { my_c = s; my_i = h; }
+    }
+    bc[threadIdx.x] = my_c; bi[threadIdx.x] = my_i;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            const uint32_t oc = bc[threadIdx.x + st], oi = bi[threadIdx.x + st];
+            if (oi != 0xFFFFFFFFu && (bi[threadIdx.x] == 0xFFFFFFFFu || oc > bc[threadIdx.x] ||
+                                      (oc == bc[threadIdx.x] && oi < bi[threadIdx.x]))) {
+                bc[threadIdx.x] = oc; bi[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { best[0] = bi[0]; best[1] = bc[0]; }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, uint8_t *__restrict__ labels,
+                                               uint32_t want, uint32_t label, const uint32_t *__restrict__ n_ptr,
+                                               uint32_t n_host, const float *__restrict__ hyp8,
+                                               const float2 *__restrict__ band, const uint32_t *__restrict__ best,
+                                               float tau)
+{
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    const uint32_t h = best[0];
+    if (h == 0xFFFFFFFFu) return;
+    const float *hy = hyp8 + 8 * (size_t)h;
+    const float a = hy[0], b = hy[1], c = hy[2], d = hy[3], e = hy[4], f = hy[5];
+    float lo2 = 0, hi2 = 0;
+    if (MODEL == 1) { const float2 bd = band[h]; lo2 = bd.x; hi2 = bd.y; }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (labels[i] != want) continue;
+        const float4 p = pts[i];
+        const bool in = MODEL == 0 ? plane_inlier(p.x, p.y, p.z, a, b, c, d, tau)
+                                   : cyl_inlier(p.x, p.y, p.z, a, b, c, d, e, f, lo2, hi2);
+        if (in) labels[i] = (uint8_t)label;
+    }
+}
+
+// mom16 = count, sum p (3), sum pp^T (6), sum nn^T (6) over points with labels == label (fp64)
+__global__ __launch_bounds__(256) void k_segment_moments(const float4 *__restrict__ pts,
+                                                         const float4 *__restrict__ nrm,
+                                                         const uint8_t *__restrict__ labels, uint32_t label,
+                                                         const uint32_t *__restrict__ n_ptr, uint32_t n_host,
+                                                         double *__restrict__ partial /* [gridDim.x][16] */)
+{
+    __shared__ double red[256 / kWave][16];
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    double m[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m[k] = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (labels && labels[i] != label) continue;
+        const float4 p = pts[i];
+        const double x = p.x, y = p.y, z = p.z;
+        m[0] += 1.0; m[1] += x; m[2] += y; m[3] += z;
+        m[4] += x * x; m[5] += x * y; m[6] += x * z; m[7] += y * y; m[8] += y * z; m[9] += z * z;
+        if (nrm) {
+            const float4 q = nrm[i];
+            const double a = q.x, b = q.y, c = q.z;
+            m[10] += a * a; m[11] += a * b; m[12] += a * c; m[13] += b * b; m[14] += b * c; m[15] += c * c;
+        }
+    }
+    const int w = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double r = wave_sum(m[k]);
+        if (lane_id() == 0) red[w][k] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double r = 0;
+#pragma unroll
+        for (int j = 0; j < 256 / kWave; ++j) r += red[j][threadIdx.x];
+        partial[(size_t)blockIdx.x * 16 + threadIdx.x] = r;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_moments_finalize(const double *__restrict__ partial, uint32_t nblocks,
+                                                         double *__restrict__ mom16)
+{
+    if (threadIdx.x < 16) {
+        double r = 0;
+        for (uint32_t b = 0; b < nblocks; ++b) r += partial[(size_t)b * 16 + threadIdx.x];
+        mom16[threadIdx.x] = r;
+    }
+}
+
+// refits + copy of the winning hypotheses into the frame record
+__global__ void k_ext_finalize(const float *__restrict__ hyp_plane, const uint32_t *__restrict__ best_plane,
+                               const float *__restrict__ hyp_cyl, const uint32_t *__restrict__ best_cyl,
+                               const double *__restrict__ mom_plane, const double *__restrict__ mom_cyl,
+                               FrameExt *__restrict__ ext)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    FrameExt e;
+    for (int k = 0; k < 4; ++k) { e.plane[k] = __builtin_nanf(""); e.plane_refit[k] = __builtin_nan(""); }
+    for (int k = 0; k < 7; ++k) e.cylinder[k] = __builtin_nanf("");
+    for (int k = 0; k < 3; ++k) e.cyl_axis_refit[k] = __builtin_nan("");
+    e.plane_inliers = 0; e.cylinder_inliers = 0;
+    if (best_plane && best_plane[0] != 0xFFFFFFFFu) {
+        const float *hy = hyp_plane + 8 * (size_t)best_plane[0];
+        for (int k = 0; k < 4; ++k) e.plane[k] = hy[k];
+        e.plane_inliers = best_plane[1];
+        const double *m = mom_plane;
+        const double n = m[0];
+        if (n >= 3.0) {
+            const double cx = m[1] / n, cy = m[2] / n, cz = m[3] / n;
+            const double C[6] = {m[4] / n - cx * cx, m[5] / n - cx * cy, m[6] / n - cx * cz,
+                                 m[7] / n - cy * cy, m[8] / n - cy * cz, m[9] / n - cz * cz};
+            double w[3], V[9];
+            jacobi_eig3(C, w, V);
+            e.plane_refit[0] = V[0]; e.plane_refit[1] = V[1]; e.plane_refit[2] = V[2];
+            e.plane_refit[3] = -(V[0] * cx + V[1] * cy + V[2] * cz);
+        }
+    }
+    if (best_cyl && best_cyl[0] != 0xFFFFFFFFu) {
+        const float *hy = hyp_cyl + 8 * (size_t)best_cyl[0];
+        for (int k = 0; k < 7; ++k) e.cylinder[k] = hy[k];
+        e.cylinder_inliers = best_cyl[1];
+        const double *m = mom_cyl;
+        const double S[6] = {m[10], m[11], m[12], m[13], m[14], m[15]};
+        double w[3], V[9];
+        jacobi_eig3(S, w, V);
+        e.cyl_axis_refit[0] = V[0]; e.cyl_axis_refit[1] = V[1]; e.cyl_axis_refit[2] = V[2];
+    }
+    *ext = e;
+}
+
+// ---- launchers -------------------------------------------------------------------
+
+uint32_t score_blocks(uint32_t n_cap) { return (n_cap + kScTile - 1) / kScTile; }
+
+void launch_plane_hypotheses(const float4 *pts, const uint8_t *labels, uint32_t want, const uint32_t *n_ptr,
+                             uint32_t n_host, uint64_t seed, uint32_t H, float *hyp8, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_plane_hypotheses, dim3((H + 255) / 256), dim3(256), 0, s, pts, labels, want, n_ptr, n_host,
+                       seed, H, hyp8);
+}
+
+void launch_cylinder_hypotheses(const float4 *pts, const float4 *nrm, const uint8_t *labels, uint32_t want,
+                                const uint32_t *n_ptr, uint32_t n_host, uint64_t seed, uint32_t H, float *hyp8,
+                                hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cylinder_hypotheses, dim3((H + 255) / 256), dim3(256), 0, s, pts, nrm, labels, want, n_ptr,
+                       n_host, seed, H, hyp8);
+}
+
+void launch_score(int model, const float4 *pts, const uint8_t *labels, uint32_t want, const uint32_t *n_ptr,
+                  uint32_t n_cap, const float *hyp8, float2 *band, uint32_t H, double tau, uint32_t *partial,
+                  int32_t *counts, uint32_t *best, hipStream_t s)
+{
+    const uint32_t nb = score_blocks(n_cap) ? score_blocks(n_cap) : 1;
+    const size_t lds = sizeof(uint32_t) * H;
+    if (model == 0) {
+        hipLaunchKernelGGL(k_score<0>, dim3(nb), dim3(kScThreads), lds, s, pts, labels, want, n_ptr, n_cap, hyp8,
+                           (const float2 *)band, H, (float)tau, partial);
+    } else {
+        hipLaunchKernelGGL(k_cyl_bands, dim3((H + 255) / 256), dim3(256), 0, s, hyp8, H, tau, band);
+        hipLaunchKernelGGL(k_score<1>, dim3(nb), dim3(kScThreads), lds, s, pts, labels, want, n_ptr, n_cap, hyp8,
+                           (const float2 *)band, H, (float)tau, partial);
+    }
+    hipLaunchKernelGGL(k_best_hypothesis, dim3(1), dim3(1024), 0, s, (const uint32_t *)partial, nb, H, counts, best);
+}
+
+void launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, uint32_t label, const uint32_t *n_ptr,
+                  uint32_t n_cap, const float *hyp8, const float2 *band, const uint32_t *best, double tau,
+                  hipStream_t s)
+{
+    uint32_t nb = (n_cap + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb == 0) nb = 1;
+    if (model == 0)
+        hipLaunchKernelGGL(k_label<0>, dim3(nb), dim3(256), 0, s, pts, labels, want, label, n_ptr, n_cap, hyp8, band,
+                           best, (float)tau);
+    else
+        hipLaunchKernelGGL(k_label<1>, dim3(nb), dim3(256), 0, s, pts, labels, want, label, n_ptr, n_cap, hyp8, band,
+                           best, (float)tau);
+}
+
+void launch_segment_moments(const float4 *pts, const float4 *nrm, const uint8_t *labels, uint32_t label,
+                            const uint32_t *n_ptr, uint32_t n_cap, double *partial, double *mom16, hipStream_t s)
+{
+    uint32_t nb = (n_cap + 255) / 256;
+    if (nb > (uint32_t)kScatterBlocks) nb = kScatterBlocks;
+    if (nb == 0) nb = 1;
+    hipLaunchKernelGGL(k_segment_moments, dim3(nb), dim3(256), 0, s, pts, nrm, labels, label, n_ptr, n_cap, partial);
+    hipLaunchKernelGGL(k_moments_finalize, dim3(1), dim3(64), 0, s, (const double *)partial, nb, mom16);
+}
+
+void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, const float *hyp_cyl,
+                         const uint32_t *best_cyl, const double *mom_plane, const double *mom_cyl, FrameExt *ext,
+                         hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ext_finalize, dim3(1), dim3(64), 0, s, hyp_plane, best_plane, hyp_cyl, best_cyl, mom_plane,
+                       mom_cyl, ext);
+}
+
+}  // namespace gm

@@ -205,25 +205,56 @@ gm_status gm_solve_local_frame(const double scatter6[6], float eigenvalues[3], f
 gm_status gm_set_owned_range(gm_ctx *ctx, double own_lo, double own_hi);
 
 /* ---- extensions without a reference counterpart (SURVEY.md par. 8a-ext) ----- */
+/* getCylinder is an empty stub in the reference (src/tunnel_processing.cpp:149-154);
+ * these follow PCL's SampleConsensusModelPlane / SampleConsensusModelCylinder
+ * conventions and are checked against oracle/gm_oracle_ext.c + analytic truth only.
+ * With GM_CFG_RANSAC_PLANE / _CYLINDER a frame additionally runs, on its valid cloud:
+ * seeded hypotheses -> batched scoring -> best model -> inlier labels (1 plane,
+ * 2 cylinder; the cylinder samples and scores only points the plane left) ->
+ * per-segment moments -> refits, reported in gm_frame_result. */
+
+int gm_ext_available(void); /* 1 when the extension kernels are built in */
+
+/* labels (may be NULL): only points with labels[i]==want take part / are sampled. */
 
 /* Score caller-supplied hypotheses against a host cloud (xyz rows of 3 floats).
- * plane rows a,b,c,d: inlier iff |a x + b y + c z + d| < tau.
+ * plane rows a,b,c,d: inlier iff |a x + b y + c z + d| < tau  (fp32, fma chain).
  * cylinder rows px,py,pz,dx,dy,dz,r: inlier iff (r-tau)^2 < dist_axis^2 < (r+tau)^2. */
-gm_status gm_score_planes(gm_ctx *ctx, const float *xyz, uint32_t n, const float *hyp4, uint32_t H,
-                          double tau, int32_t *counts);
-gm_status gm_score_cylinders(gm_ctx *ctx, const float *xyz, uint32_t n, const float *hyp7, uint32_t H,
-                             double tau, int32_t *counts);
-/* Seeded minimal-sample hypotheses generated on the device. */
-gm_status gm_plane_hypotheses(gm_ctx *ctx, const float *xyz, uint32_t n, uint64_t seed, uint32_t H, float *hyp4);
+gm_status gm_score_planes(gm_ctx *ctx, const float *xyz, uint32_t n, const uint8_t *labels, uint32_t want,
+                          const float *hyp4, uint32_t H, double tau, int32_t *counts);
+gm_status gm_score_cylinders(gm_ctx *ctx, const float *xyz, uint32_t n, const uint8_t *labels, uint32_t want,
+                             const float *hyp7, uint32_t H, double tau, int32_t *counts);
+/* Seeded minimal-sample hypotheses generated on the device (splitmix64 counter PRNG). */
+gm_status gm_plane_hypotheses(gm_ctx *ctx, const float *xyz, uint32_t n, const uint8_t *labels, uint32_t want,
+                              uint64_t seed, uint32_t H, float *hyp4);
 gm_status gm_cylinder_hypotheses(gm_ctx *ctx, const float *xyz, const float *nxyzc, uint32_t n,
-                                 uint64_t seed, uint32_t H, float *hyp7);
-/* Per-segment moments: mom16 = count, sum p (3), sum pp^T (6), sum nn^T (6). */
+                                 const uint8_t *labels, uint32_t want, uint64_t seed, uint32_t H, float *hyp7);
+/* Per-segment moments over points with labels[i]==label (labels NULL: all points):
+ * mom16 = count, sum p (3), sum pp^T (xx,xy,xz,yy,yz,zz), sum nn^T (same order); fp64. */
 gm_status gm_segment_moments(gm_ctx *ctx, const float *xyz, const float *nxyzc, const uint8_t *labels,
                              uint32_t n, uint32_t label, double mom16[16]);
 
-/* Compressed map record of a completed slot (build-defined format):
- * header + primitive records + voxel centroids.  Returns bytes needed in
+/* "Compressed map" record of a completed slot.  The reference defines no such
+ * output; this is a build-defined format: header, primitive records,
+ * then n_voxels rows of x,y,z,count (float32).  Returns the bytes needed in
  * *n_bytes (also on GM_ERR_CAPACITY). */
+typedef struct gm_map_header {
+    char     magic[4];       /* "GMAP" */
+    uint32_t version;        /* 1 */
+    uint32_t n_primitives;
+    uint32_t n_voxels;
+    float    leaf, bound;
+    uint32_t n_points;       /* valid points the map was built from */
+    uint32_t reserved;
+    float    eigenvalues[3];
+    float    center_axis[3];
+} gm_map_header;
+typedef struct gm_map_primitive {
+    uint32_t type;           /* 1 plane (a,b,c,d refit), 2 cylinder (point, axis, radius) */
+    uint32_t inliers;
+    float    params[7];
+    float    pad;
+} gm_map_primitive;
 gm_status gm_get_compressed_map(gm_ctx *ctx, uint32_t slot, void *buf, size_t capacity, size_t *n_bytes);
 
 #ifdef __cplusplus

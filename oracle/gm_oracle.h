@@ -96,9 +96,11 @@ uint64_t gmo_mix64(uint64_t x);
  * cylinder: 2 points + their normals -> (px,py,pz, dx,dy,dz, r)
  *        (PCL SampleConsensusModelCylinder::computeModelCoefficients).
  * A degenerate sample yields a hypothesis of NaNs (scores 0 inliers). */
-void gmo_plane_hypotheses(const float *xyz, int n, uint64_t seed, int H, float *hyp4);
-void gmo_cylinder_hypotheses(const float *xyz, const float *normals, int n, uint64_t seed,
-                             int H, float *hyp7);
+/* labels (may be NULL): samples are drawn only from points with labels[i]==want. */
+void gmo_plane_hypotheses(const float *xyz, int n, const uint8_t *labels, int want, uint64_t seed, int H,
+                          float *hyp4);
+void gmo_cylinder_hypotheses(const float *xyz, const float *normals, int n, const uint8_t *labels, int want,
+                             uint64_t seed, int H, float *hyp7);
 
 /* inlier counts: plane |n.p+d| < tau ; cylinder |dist(p,axis)-r| < tau.
  * mask (may be NULL): only points with mask[i]==want participate. */

@@ -37,16 +37,35 @@ static uint32_t draw_index(uint64_t seed, uint32_t h, uint32_t t, uint32_t n)
 
 static void set_nan(float *p, int k) { for (int i = 0; i < k; i++) p[i] = NAN; }
 
-void gmo_plane_hypotheses(const float *xyz, int n, uint64_t seed, int H, float *hyp4)
+#define GMO_MAX_DRAWS 64u
+
+/* next index of hypothesis h that lies in the wanted segment (labels==NULL: any)
+ * and differs from a and b; advances *t; returns 0xFFFFFFFF when the draw budget
+ * is spent */
+static uint32_t next_sample(uint64_t seed, uint32_t h, uint32_t *t, uint32_t n, const uint8_t *labels, int want,
+                            uint32_t a, uint32_t b)
+{
+    while (*t < GMO_MAX_DRAWS) {
+        uint32_t i = draw_index(seed, h, (*t)++, n);
+        if (i == a || i == b) continue;
+        if (labels && labels[i] != want) continue;
+        return i;
+    }
+    return 0xFFFFFFFFu;
+}
+
+void gmo_plane_hypotheses(const float *xyz, int n, const uint8_t *labels, int want, uint64_t seed, int H,
+                          float *hyp4)
 {
     for (int h = 0; h < H; h++) {
         float *o = hyp4 + 4 * (size_t)h;
         if (n < 3) { set_nan(o, 4); continue; }
-        uint32_t t = 0, i0, i1, i2;
-        i0 = draw_index(seed, (uint32_t)h, t++, (uint32_t)n);
-        do { i1 = draw_index(seed, (uint32_t)h, t++, (uint32_t)n); } while (i1 == i0 && t < 16);
-        do { i2 = draw_index(seed, (uint32_t)h, t++, (uint32_t)n); } while ((i2 == i0 || i2 == i1) && t < 32);
-        if (i1 == i0 || i2 == i0 || i2 == i1) { set_nan(o, 4); continue; }
+        uint32_t t = 0;
+        const uint32_t none = 0xFFFFFFFFu;
+        uint32_t i0 = next_sample(seed, (uint32_t)h, &t, (uint32_t)n, labels, want, none, none);
+        uint32_t i1 = i0 == none ? none : next_sample(seed, (uint32_t)h, &t, (uint32_t)n, labels, want, i0, none);
+        uint32_t i2 = i1 == none ? none : next_sample(seed, (uint32_t)h, &t, (uint32_t)n, labels, want, i0, i1);
+        if (i2 == none) { set_nan(o, 4); continue; }
         const float *p0 = xyz + 3 * (size_t)i0, *p1 = xyz + 3 * (size_t)i1, *p2 = xyz + 3 * (size_t)i2;
         double ax = (double)p1[0] - p0[0], ay = (double)p1[1] - p0[1], az = (double)p1[2] - p0[2];
         double bx = (double)p2[0] - p0[0], by = (double)p2[1] - p0[1], bz = (double)p2[2] - p0[2];
@@ -59,16 +78,17 @@ void gmo_plane_hypotheses(const float *xyz, int n, uint64_t seed, int H, float *
     }
 }
 
-void gmo_cylinder_hypotheses(const float *xyz, const float *normals, int n, uint64_t seed,
-                             int H, float *hyp7)
+void gmo_cylinder_hypotheses(const float *xyz, const float *normals, int n, const uint8_t *labels, int want,
+                             uint64_t seed, int H, float *hyp7)
 {
     for (int h = 0; h < H; h++) {
         float *o = hyp7 + 7 * (size_t)h;
         if (n < 2) { set_nan(o, 7); continue; }
-        uint32_t t = 0, i0, i1;
-        i0 = draw_index(seed, (uint32_t)h, t++, (uint32_t)n);
-        do { i1 = draw_index(seed, (uint32_t)h, t++, (uint32_t)n); } while (i1 == i0 && t < 16);
-        if (i1 == i0) { set_nan(o, 7); continue; }
+        uint32_t t = 0;
+        const uint32_t none = 0xFFFFFFFFu;
+        uint32_t i0 = next_sample(seed, (uint32_t)h, &t, (uint32_t)n, labels, want, none, none);
+        uint32_t i1 = i0 == none ? none : next_sample(seed, (uint32_t)h, &t, (uint32_t)n, labels, want, i0, none);
+        if (i1 == none) { set_nan(o, 7); continue; }
         const float *p1 = xyz + 3 * (size_t)i0, *p2 = xyz + 3 * (size_t)i1;
         const float *n1 = normals + 4 * (size_t)i0, *n2 = normals + 4 * (size_t)i1;
         /* closest points of the two normal lines (p1+n1)+s*n1 and p2+t*n2 */

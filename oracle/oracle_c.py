@@ -50,8 +50,8 @@ def lib():
                                         fp, fp, fp, C.POINTER(FrameResult)]
         L.gmo_process_frame.restype = C.c_int
         L.gmo_mix64.argtypes = [C.c_uint64]; L.gmo_mix64.restype = C.c_uint64
-        L.gmo_plane_hypotheses.argtypes = [fp, C.c_int, C.c_uint64, C.c_int, fp]; L.gmo_plane_hypotheses.restype = None
-        L.gmo_cylinder_hypotheses.argtypes = [fp, fp, C.c_int, C.c_uint64, C.c_int, fp]; L.gmo_cylinder_hypotheses.restype = None
+        L.gmo_plane_hypotheses.argtypes = [fp, C.c_int, u8p, C.c_int, C.c_uint64, C.c_int, fp]; L.gmo_plane_hypotheses.restype = None
+        L.gmo_cylinder_hypotheses.argtypes = [fp, fp, C.c_int, u8p, C.c_int, C.c_uint64, C.c_int, fp]; L.gmo_cylinder_hypotheses.restype = None
         L.gmo_score_planes.argtypes = [fp, C.c_int, u8p, C.c_int, fp, C.c_int, C.c_double, ip]; L.gmo_score_planes.restype = None
         L.gmo_score_cylinders.argtypes = [fp, C.c_int, u8p, C.c_int, fp, C.c_int, C.c_double, ip]; L.gmo_score_cylinders.restype = None
         L.gmo_label_plane.argtypes = [fp, C.c_int, u8p, C.c_int, C.c_int, fp, C.c_double]; L.gmo_label_plane.restype = C.c_int
@@ -168,18 +168,22 @@ def process_frame(xyz, bound, radius, leaf, wf, mode=F64, nthreads=1, want_outpu
 
 # ---- extensions ----
 
-def plane_hypotheses(xyz, seed, H):
+def plane_hypotheses(xyz, seed, H, labels=None, want=0):
     xyz = _xyz(xyz)
     out = np.empty((H, 4), dtype=np.float32)
-    lib().gmo_plane_hypotheses(_f(xyz), len(xyz), C.c_uint64(seed), H, _f(out))
+    if labels is not None:
+        labels = np.ascontiguousarray(labels, dtype=np.uint8)
+    lib().gmo_plane_hypotheses(_f(xyz), len(xyz), _u8(labels), want, C.c_uint64(seed), H, _f(out))
     return out
 
 
-def cylinder_hypotheses(xyz, nrm, seed, H):
+def cylinder_hypotheses(xyz, nrm, seed, H, labels=None, want=0):
     xyz = _xyz(xyz)
     nrm = np.ascontiguousarray(nrm, dtype=np.float32)
     out = np.empty((H, 7), dtype=np.float32)
-    lib().gmo_cylinder_hypotheses(_f(xyz), _f(nrm), len(xyz), C.c_uint64(seed), H, _f(out))
+    if labels is not None:
+        labels = np.ascontiguousarray(labels, dtype=np.uint8)
+    lib().gmo_cylinder_hypotheses(_f(xyz), _f(nrm), len(xyz), _u8(labels), want, C.c_uint64(seed), H, _f(out))
     return out
 
 

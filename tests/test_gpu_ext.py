@@ -1,0 +1,160 @@
+"""GPU tests of the build-defined extensions (RANSAC scoring, labels, moments,
+refits, 1-NN, compressed map).  The reference has no counterpart
+(getCylinder is a stub, /root/reference src/tunnel_processing.cpp:149-154):
+parity here is vs the build's own CPU restatement + analytic truth of the
+synthetic generator -- never "vs reference".
+
+Tolerances: inlier counts and labels bit-exact (integer work, same fp32 fma
+chain on both sides); hypotheses 1e-6 (double arithmetic, fp contraction may
+differ); moments 1e-12 relative (fp64 sums, different order).
+"""
+import numpy as np
+import pytest
+
+from geometric_mapping_amd import synth
+
+pytestmark = pytest.mark.gpu
+B, R, LEAF, WF, TAU = 5.0, 0.5, 0.5, 0.2, 0.03
+
+
+def ang(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    s = np.linalg.norm(np.cross(a, b)) / (np.linalg.norm(a) * np.linalg.norm(b))
+    return float(np.arcsin(min(1.0, s)))
+
+
+@pytest.fixture(scope="module")
+def ctx(gm):
+    c = gm.GeometricMapping()
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def scene(oc):
+    xyz = synth.tunnel_frame(40000, seed=8, floor_z=-1.2, outlier_frac=0.01)
+    xyz = xyz[oc.crop_box(xyz, B)]
+    nrm, _ = oc.normals(xyz, R, oc.F64)
+    keep = oc.finite_normals(nrm)
+    return xyz[keep], nrm[keep]
+
+
+def test_hypotheses_match_oracle(ctx, oc, scene):
+    xyz, nrm = scene
+    labels = (np.arange(len(xyz)) % 3 == 0).astype(np.uint8)
+    for lab, want in ((None, 0), (labels, 0), (labels, 1)):
+        hp = ctx.plane_hypotheses(xyz, 42, 512, lab, want)
+        op = oc.plane_hypotheses(xyz, 42, 512, lab, want)
+        assert np.array_equal(np.isnan(hp), np.isnan(op))
+        ok = np.isfinite(op[:, 0])
+        assert ok.mean() > 0.95 and np.abs(hp[ok] - op[ok]).max() < 1e-5
+        hc = ctx.cylinder_hypotheses(xyz, nrm, 43, 512, lab, want)
+        ocy = oc.cylinder_hypotheses(xyz, nrm, 43, 512, lab, want)
+        assert np.array_equal(np.isnan(hc), np.isnan(ocy))
+        ok = np.isfinite(ocy[:, 0]) & (np.abs(ocy[:, :3]).max(axis=1) < 1e3)
+        rel = np.abs(hc[ok] - ocy[ok]) / np.maximum(np.abs(ocy[ok]), 1.0)
+        assert np.quantile(rel, 0.99) < 1e-4      # ill-conditioned samples amplify the last double bits
+
+
+def test_scoring_counts_bit_exact(ctx, oc, scene):
+    xyz, nrm = scene
+    hp = oc.plane_hypotheses(xyz, 1, 1024)
+    hc = oc.cylinder_hypotheses(xyz, nrm, 2, 1024)
+    labels = (np.arange(len(xyz)) % 4 == 1).astype(np.uint8)
+    for lab, want in ((None, 0), (labels, 1), (labels, 0)):
+        assert np.array_equal(ctx.score_planes(xyz, hp, TAU, lab, want), oc.score_planes(xyz, hp, TAU, lab, want))
+        assert np.array_equal(ctx.score_cylinders(xyz, hc, TAU, lab, want), oc.score_cylinders(xyz, hc, TAU, lab, want))
+    # ragged sizes around the per-block tile, tiny H, empty cloud
+    for n in (0, 1, 63, 64, 2047, 2048, 2049):
+        a = ctx.score_planes(xyz[:n], hp[:7], TAU)
+        assert np.array_equal(a, oc.score_planes(xyz[:n], hp[:7], TAU))
+    nanhyp = np.full((3, 4), np.nan, np.float32)
+    assert ctx.score_planes(xyz, nanhyp, TAU).tolist() == [0, 0, 0]
+
+
+def test_scoring_known_answer_perfect_models(ctx):
+    pl = synth.plane_patch(5000, seed=3, normal=(0, 0, 1), offset=-1.2, half=3.0)
+    assert ctx.score_planes(pl, np.array([[0, 0, 1, 1.2], [0, 0, 1, 1.3]], np.float32), TAU).tolist() == [5000, 0]
+    cy = synth.cylinder_frame(5000, seed=5, sigma=0.0)
+    h = np.array([[0, 0, 0, 1, 0, 0, 2.0], [0, 0, 0, 1, 0, 0, 2.1], [0, 0, 0.5, 1, 0, 0, 2.0]], np.float32)
+    c = ctx.score_cylinders(cy, h, TAU)
+    assert c[0] == 5000 and c[1] == 0 and 0 < c[2] < 5000
+
+
+def test_segment_moments(ctx, oc, scene):
+    xyz, nrm = scene
+    labels = (np.arange(len(xyz)) % 3).astype(np.uint8)
+    for lab, k in ((labels, 1), (labels, 2), (None, 0)):
+        a = ctx.segment_moments(xyz, nrm, lab, k)
+        b = oc.segment_moments(xyz, nrm, lab, k)
+        assert a[0] == b[0]
+        assert np.abs(a - b).max() / np.abs(b).max() < 1e-12
+
+
+def test_nearest(ctx, oc):
+    xyz = synth.cylinder_frame(30000, seed=11)
+    cen, _, _, _ = oc.voxel_grid(xyz, LEAF)
+    a = ctx.nearest(xyz, cen)
+    b = oc.nearest(xyz, cen)
+    assert np.array_equal(a, b)                      # same fp32 distance, lowest index on ties
+    assert ctx.nearest(xyz[:1], cen).tolist() == [0] * len(cen)
+
+
+def test_frame_ransac_plane_then_cylinder(gm, oc):
+    from geometric_mapping_amd import _lib
+    xyz = synth.tunnel_frame(60000, seed=2, floor_z=-1.2, outlier_frac=0.01)
+    H, seed = 512, 7
+    flags = _lib.GM_CFG_DEFAULT | _lib.GM_CFG_RANSAC_PLANE | _lib.GM_CFG_RANSAC_CYLINDER | _lib.GM_CFG_NEAREST
+    with gm.GeometricMapping(flags=flags, ransac_hypotheses=H, ransac_threshold=TAU, ransac_seed=seed) as c:
+        res = c.process_frame(xyz)
+        cloud, _ = c.cropped_cloud()
+        nrm = c.normals()
+        lab = c.labels()
+        nn = c.voxel_nearest()
+        cen, _ = c.voxel_centroids()
+        blob = c.compressed_map()
+    # the same sequence on the CPU restatement, fed the GPU's own cloud+normals
+    labels = np.zeros(len(cloud), np.uint8)
+    hp = oc.plane_hypotheses(cloud, seed, H, labels, 0)
+    cp = oc.score_planes(cloud, hp, TAU, labels, 0)
+    bp = int(np.argmax(cp))
+    assert res["plane_inliers"] == cp[bp]
+    assert np.abs(res["plane"] - hp[bp]).max() < 1e-5
+    assert oc.label_plane(cloud, labels, 0, 1, res["plane"], TAU) == res["plane_inliers"]
+    hc = oc.cylinder_hypotheses(cloud, nrm, seed + 1, H, labels, 0)
+    cc = oc.score_cylinders(cloud, hc, TAU, labels, 0)
+    bc = int(np.argmax(cc))
+    assert abs(int(res["cylinder_inliers"]) - int(cc[bc])) <= 2     # hypotheses agree to 1e-6, not bit for bit
+    assert oc.label_cylinder(cloud, labels, 0, 2, res["cylinder"], TAU) == res["cylinder_inliers"]
+    assert np.array_equal(lab, labels)
+    # refits vs the restatement on the same labels
+    assert np.abs(res["plane_refit"] - oc.refit_plane(oc.segment_moments(cloud, nrm, labels, 1))).max() < 1e-9 or \
+        np.abs(res["plane_refit"] + oc.refit_plane(oc.segment_moments(cloud, nrm, labels, 1))).max() < 1e-9
+    assert ang(res["cylinder_axis_refit"], oc.refit_axis(oc.segment_moments(cloud, nrm, labels, 2))) < 1e-9
+    # analytic truth of the generator: floor z=-1.2, tunnel R=2 along x
+    assert abs(abs(res["plane_refit"][2]) - 1) < 1e-4 and abs(abs(res["plane_refit"][3]) - 1.2) < 3e-3
+    assert abs(res["cylinder"][6] - 2.0) < 0.05 and ang(res["cylinder"][3:6], [1, 0, 0]) < 0.05
+    assert ang(res["cylinder_axis_refit"], [1, 0, 0]) < 5e-3
+    assert res["plane_inliers"] > 5000 and res["cylinder_inliers"] > 20000
+    # 1-NN of the voxel centroids
+    assert np.array_equal(nn, oc.nearest(cloud, cen))
+    # compressed map round trip
+    m = gm.decode_compressed_map(blob)
+    assert m["n_points"] == res["n_valid"] and len(m["voxels"]) == res["n_voxels"]
+    assert np.array_equal(m["voxels"][:, :3], cen)
+    assert [p["type"] for p in m["primitives"]] == [1, 2]
+    assert m["primitives"][0]["inliers"] == res["plane_inliers"]
+    assert np.allclose(m["primitives"][1]["params"], res["cylinder"])
+    assert np.allclose(m["center_axis"], res["center_axis"])
+
+
+def test_frame_ransac_cylinder_only_is_deterministic(gm):
+    from geometric_mapping_amd import _lib
+    xyz = synth.tunnel_frame(50000, seed=4)
+    flags = _lib.GM_CFG_DEFAULT | _lib.GM_CFG_RANSAC_CYLINDER
+    with gm.GeometricMapping(flags=flags, ransac_hypotheses=256) as c:
+        a = c.process_frame(xyz)
+        b = c.process_frame(xyz)
+    assert a["cylinder_inliers"] == b["cylinder_inliers"] and np.array_equal(a["cylinder"], b["cylinder"])
+    assert a["plane_inliers"] == 0 and np.isnan(a["plane"]).all()
+    assert abs(a["cylinder"][6] - 2.0) < 0.05

@@ -309,8 +309,7 @@ def test_sequential_labels_and_refit(oc):
     n_pl = oc.label_plane(xyz, labels, 0, 1, best, 0.03)
     assert n_pl == cp.max() and (labels == 1).sum() == n_pl
     assert abs(abs(best[2]) - 1) < 1e-2 and abs(abs(best[3]) - 1.2) < 5e-2
-    rest = labels == 0
-    hc = oc.cylinder_hypotheses(xyz[rest], nrm[rest], 2, 256)
+    hc = oc.cylinder_hypotheses(xyz, nrm, 2, 256, labels, 0)   # samples only from unassigned points
     cc = oc.score_cylinders(xyz, hc, 0.03, labels, 0)
     bc = hc[np.argmax(cc)]
     n_cy = oc.label_cylinder(xyz, labels, 0, 2, bc, 0.03)
