@@ -165,64 +165,76 @@ __device__ __forceinline__ bool cyl_inlier(float x, float y, float z, float px, 
     return q > lo2 && q < hi2;
 }
 
-// MODEL 0: plane, 1: cylinder.  partial[blockIdx.x][h] = inliers of hypothesis h among this block's points.
+// MODEL 0: plane, 1: cylinder.  Block (x, y) scores hypotheses [y*256, y*256+256) against points
+// [x*kScTile, +kScTile).  lane <-> hypothesis: each lane keeps ITS hypothesis in registers and a
+// private inlier counter; the block's points are staged once in LDS (coalesced 16 B loads, masked
+// points become NaN) and every lane walks them through broadcast ds_read_b128.  The inner loop is
+// pure VALU (3 fma + cmp + add-carry for a plane): no ballots, no SALU, no atomics; one integer
+// atomicAdd per (block, hypothesis) at the end (integer adds commute: exact, run-to-run identical).
+constexpr int kScHC = kScThreads;
+
 template <int MODEL>
 __global__ __launch_bounds__(kScThreads) void k_score(const float4 *__restrict__ pts,
                                                       const uint8_t *__restrict__ labels, uint32_t want,
                                                       const uint32_t *__restrict__ n_ptr, uint32_t n_host,
                                                       const float *__restrict__ hyp8,
                                                       const float2 *__restrict__ band, uint32_t H, float tau,
-                                                      uint32_t *__restrict__ partial)
+                                                      int32_t *__restrict__ counts)
 {
-    extern __shared__ uint32_t lcnt[];  // [H]
+    __shared__ float4 lp[kScTile];
     const uint32_t n = n_ptr ? *n_ptr : n_host;
     const uint32_t base = blockIdx.x * kScTile;
-    for (uint32_t h = threadIdx.x; h < H; h += kScThreads) lcnt[h] = 0;
-    __syncthreads();
-    if (base < n) {
-        float px[kScP], py[kScP], pz[kScP];
+    if (base >= n) return;  // uniform per block
+    const uint32_t m = (n - base < (uint32_t)kScTile) ? n - base : (uint32_t)kScTile;
+    const uint32_t m4 = (m + 3u) & ~3u;
 #pragma unroll
-        for (int p = 0; p < kScP; ++p) {
-            const uint32_t i = base + p * kScThreads + threadIdx.x;
-            bool ok = i < n;
-            if (ok && labels) ok = labels[i] == want;
-            float4 v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 0.f);
-            if (ok) v = pts[i];
-            px[p] = v.x; py[p] = v.y; pz[p] = v.z;
-        }
-        for (uint32_t h = 0; h < H; ++h) {
-            const float *hy = hyp8 + 8 * (size_t)h;  // wave-uniform address: scalar loads
-            uint32_t c = 0;
-            if (MODEL == 0) {
-                const float a = hy[0], b = hy[1], cc = hy[2], d = hy[3];
-#pragma unroll
-                for (int p = 0; p < kScP; ++p)
-                    c += (uint32_t)__popcll(__ballot(plane_inlier(px[p], py[p], pz[p], a, b, cc, d, tau)));
-            } else {
-                const float qx = hy[0], qy = hy[1], qz = hy[2], dx = hy[3], dy = hy[4], dz = hy[5];
-                const float2 bd = band[h];
-#pragma unroll
-                for (int p = 0; p < kScP; ++p)
-                    c += (uint32_t)__popcll(__ballot(cyl_inlier(px[p], py[p], pz[p], qx, qy, qz, dx, dy, dz, bd.x, bd.y)));
-            }
-            if (lane_id() == 0 && c) atomicAdd(&lcnt[h], c);
+    for (int p = 0; p < kScP; ++p) {
+        const uint32_t j = p * kScThreads + threadIdx.x;
+        const uint32_t i = base + j;
+        bool ok = i < n;
+        if (ok && labels) ok = labels[i] == want;
+        float4 v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 0.f);
+        if (ok) v = pts[i];  // masked / out-of-range points are NaN: never an inlier
+        lp[j] = v;
+    }
+    const uint32_t h = blockIdx.y * kScHC + threadIdx.x;
+    float h0 = __builtin_nanf(""), h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, lo2 = 0, hi2 = 0;
+    if (h < H) {
+        const float4 a = *reinterpret_cast<const float4 *>(hyp8 + 8 * (size_t)h);
+        h0 = a.x; h1 = a.y; h2 = a.z; h3 = a.w;
+        if (MODEL == 1) {
+            const float4 b = *reinterpret_cast<const float4 *>(hyp8 + 8 * (size_t)h + 4);
+            const float2 bd = band[h];
+            h4 = b.x; h5 = b.y; lo2 = bd.x; hi2 = bd.y;
         }
     }
     __syncthreads();
-    for (uint32_t h = threadIdx.x; h < H; h += kScThreads) partial[(size_t)blockIdx.x * H + h] = lcnt[h];
+    uint32_t c = 0;
+    for (uint32_t j = 0; j < m4; j += 4) {
+        const float4 p0 = lp[j], p1 = lp[j + 1], p2 = lp[j + 2], p3 = lp[j + 3];  // broadcast reads
+        if (MODEL == 0) {
+            c += plane_inlier(p0.x, p0.y, p0.z, h0, h1, h2, h3, tau) ? 1u : 0u;
+            c += plane_inlier(p1.x, p1.y, p1.z, h0, h1, h2, h3, tau) ? 1u : 0u;
+            c += plane_inlier(p2.x, p2.y, p2.z, h0, h1, h2, h3, tau) ? 1u : 0u;
+            c += plane_inlier(p3.x, p3.y, p3.z, h0, h1, h2, h3, tau) ? 1u : 0u;
+        } else {
+            c += cyl_inlier(p0.x, p0.y, p0.z, h0, h1, h2, h3, h4, h5, lo2, hi2) ? 1u : 0u;
+            c += cyl_inlier(p1.x, p1.y, p1.z, h0, h1, h2, h3, h4, h5, lo2, hi2) ? 1u : 0u;
+            c += cyl_inlier(p2.x, p2.y, p2.z, h0, h1, h2, h3, h4, h5, lo2, hi2) ? 1u : 0u;
+            c += cyl_inlier(p3.x, p3.y, p3.z, h0, h1, h2, h3, h4, h5, lo2, hi2) ? 1u : 0u;
+        }
+    }
+    if (h < H && c) atomicAdd(&counts[h], (int32_t)c);
 }
 
-// fixed-order column sums + arg-max (largest count, lowest index on ties)
-__global__ __launch_bounds__(1024) void k_best_hypothesis(const uint32_t *__restrict__ partial, uint32_t nblocks,
-                                                          uint32_t H, int32_t *__restrict__ counts,
+// arg-max over the hypothesis counts (largest count, lowest index on ties)
+__global__ __launch_bounds__(1024) void k_best_hypothesis(const int32_t *__restrict__ counts, uint32_t H,
                                                           uint32_t *__restrict__ best /* [2]: index, count */)
 {
     __shared__ uint32_t bc[1024], bi[1024];
     uint32_t my_c = 0, my_i = 0xFFFFFFFFu;
     for (uint32_t h = threadIdx.x; h < H; h += 1024) {
-        uint32_t s = 0;
-        for (uint32_t b = 0; b < nblocks; ++b) s += partial[(size_t)b * H + h];
-        counts[h] = (int32_t)s;
+        const uint32_t s = (uint32_t)counts[h];
         if (my_i == 0xFFFFFFFFu || s > my_c) { my_c = s; my_i = h; }
     }
     bc[threadIdx.x] = my_c; bi[threadIdx.x] = my_i;
@@ -302,13 +314,21 @@ __global__ __launch_bounds__(256) void k_segment_moments(const float4 *__restric
     }
 }
 
-__global__ __launch_bounds__(64) void k_moments_finalize(const double *__restrict__ partial, uint32_t nblocks,
-                                                         double *__restrict__ mom16)
+__global__ __launch_bounds__(256) void k_moments_finalize(const double *__restrict__ partial, uint32_t nblocks,
+                                                          double *__restrict__ mom16)
 {
+    // fixed-order: thread t sums rows t, t+16, ... of column (t & 15); then a 16-way tree per column
+    __shared__ double red[16][16];
+    const int col = threadIdx.x & 15, part = threadIdx.x >> 4;
+    double r = 0;
+    for (uint32_t b = part; b < nblocks; b += 16) r += partial[(size_t)b * 16 + col];
+    red[part][col] = r;
+    __syncthreads();
     if (threadIdx.x < 16) {
-        double r = 0;
-        for (uint32_t b = 0; b < nblocks; ++b) r += partial[(size_t)b * 16 + threadIdx.x];
-        mom16[threadIdx.x] = r;
+        double t = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        mom16[threadIdx.x] = t;
     }
 }
 
@@ -376,17 +396,19 @@ void launch_score(int model, const float4 *pts, const uint8_t *labels, uint32_t 
                   uint32_t n_cap, const float *hyp8, float2 *band, uint32_t H, double tau, uint32_t *partial,
                   int32_t *counts, uint32_t *best, hipStream_t s)
 {
+    (void)partial;
     const uint32_t nb = score_blocks(n_cap) ? score_blocks(n_cap) : 1;
-    const size_t lds = sizeof(uint32_t) * H;
+    const dim3 grid(nb, (H + kScHC - 1) / kScHC);
+    hipMemsetAsync(counts, 0, sizeof(int32_t) * H, s);
     if (model == 0) {
-        hipLaunchKernelGGL(k_score<0>, dim3(nb), dim3(kScThreads), lds, s, pts, labels, want, n_ptr, n_cap, hyp8,
-                           (const float2 *)band, H, (float)tau, partial);
+        hipLaunchKernelGGL(k_score<0>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
+                           (const float2 *)band, H, (float)tau, counts);
     } else {
         hipLaunchKernelGGL(k_cyl_bands, dim3((H + 255) / 256), dim3(256), 0, s, hyp8, H, tau, band);
-        hipLaunchKernelGGL(k_score<1>, dim3(nb), dim3(kScThreads), lds, s, pts, labels, want, n_ptr, n_cap, hyp8,
-                           (const float2 *)band, H, (float)tau, partial);
+        hipLaunchKernelGGL(k_score<1>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
+                           (const float2 *)band, H, (float)tau, counts);
     }
-    hipLaunchKernelGGL(k_best_hypothesis, dim3(1), dim3(1024), 0, s, (const uint32_t *)partial, nb, H, counts, best);
+    hipLaunchKernelGGL(k_best_hypothesis, dim3(1), dim3(1024), 0, s, (const int32_t *)counts, H, best);
 }
 
 void launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, uint32_t label, const uint32_t *n_ptr,
@@ -408,10 +430,10 @@ void launch_segment_moments(const float4 *pts, const float4 *nrm, const uint8_t 
                             const uint32_t *n_ptr, uint32_t n_cap, double *partial, double *mom16, hipStream_t s)
 {
     uint32_t nb = (n_cap + 255) / 256;
-    if (nb > (uint32_t)kScatterBlocks) nb = kScatterBlocks;
+    if (nb > 256u) nb = 256u;
     if (nb == 0) nb = 1;
     hipLaunchKernelGGL(k_segment_moments, dim3(nb), dim3(256), 0, s, pts, nrm, labels, label, n_ptr, n_cap, partial);
-    hipLaunchKernelGGL(k_moments_finalize, dim3(1), dim3(64), 0, s, (const double *)partial, nb, mom16);
+    hipLaunchKernelGGL(k_moments_finalize, dim3(1), dim3(256), 0, s, (const double *)partial, nb, mom16);
 }
 
 void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, const float *hyp_cyl,
