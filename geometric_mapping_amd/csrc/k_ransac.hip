@@ -21,7 +21,7 @@
 namespace gm {
 
 constexpr int kScThreads = 256;
-constexpr int kScP = 8;                       // points per lane
+constexpr int kScP = 4;                       // points staged per thread
 constexpr int kScTile = kScThreads * kScP;    // points per block
 constexpr int kMaxDraws = 64;
 
@@ -171,7 +171,8 @@ __device__ __forceinline__ bool cyl_inlier(float x, float y, float z, float px, 
 // points become NaN) and every lane walks them through broadcast ds_read_b128.  The inner loop is
 // pure VALU (3 fma + cmp + add-carry for a plane): no ballots, no SALU, no atomics; one integer
 // atomicAdd per (block, hypothesis) at the end (integer adds commute: exact, run-to-run identical).
-constexpr int kScHC = kScThreads;
+constexpr int kScHPL = 2;                      // hypotheses per lane: amortises each LDS point read
+constexpr int kScHC = kScThreads * kScHPL;     // hypotheses per block
 
 template <int MODEL>
 __global__ __launch_bounds__(kScThreads) void k_score(const float4 *__restrict__ pts,
@@ -181,12 +182,14 @@ __global__ __launch_bounds__(kScThreads) void k_score(const float4 *__restrict__
                                                       const float2 *__restrict__ band, uint32_t H, float tau,
                                                       int32_t *__restrict__ counts)
 {
-    __shared__ float4 lp[kScTile];
+    // points in LDS as groups of four, SoA inside a group: x0..x3 | y0..y3 | z0..z3, so three
+    // broadcast ds_read_b128 deliver four points
+    __shared__ float4 lp[kScTile / 4][3];
     const uint32_t n = n_ptr ? *n_ptr : n_host;
     const uint32_t base = blockIdx.x * kScTile;
     if (base >= n) return;  // uniform per block
     const uint32_t m = (n - base < (uint32_t)kScTile) ? n - base : (uint32_t)kScTile;
-    const uint32_t m4 = (m + 3u) & ~3u;
+    const uint32_t groups = (m + 3u) >> 2;
 #pragma unroll
     for (int p = 0; p < kScP; ++p) {
         const uint32_t j = p * kScThreads + threadIdx.x;
@@ -195,36 +198,49 @@ __global__ __launch_bounds__(kScThreads) void k_score(const float4 *__restrict__
         if (ok && labels) ok = labels[i] == want;
         float4 v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 0.f);
         if (ok) v = pts[i];  // masked / out-of-range points are NaN: never an inlier
-        lp[j] = v;
+        float *g = reinterpret_cast<float *>(&lp[j >> 2][0]);
+        g[(j & 3)] = v.x; g[4 + (j & 3)] = v.y; g[8 + (j & 3)] = v.z;
     }
-    const uint32_t h = blockIdx.y * kScHC + threadIdx.x;
-    float h0 = __builtin_nanf(""), h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, lo2 = 0, hi2 = 0;
-    if (h < H) {
-        const float4 a = *reinterpret_cast<const float4 *>(hyp8 + 8 * (size_t)h);
-        h0 = a.x; h1 = a.y; h2 = a.z; h3 = a.w;
-        if (MODEL == 1) {
-            const float4 b = *reinterpret_cast<const float4 *>(hyp8 + 8 * (size_t)h + 4);
-            const float2 bd = band[h];
-            h4 = b.x; h5 = b.y; lo2 = bd.x; hi2 = bd.y;
+    float hp[kScHPL][8];
+    uint32_t c[kScHPL];
+#pragma unroll
+    for (int k = 0; k < kScHPL; ++k) {
+        const uint32_t h = blockIdx.y * kScHC + k * kScThreads + threadIdx.x;
+        c[k] = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hp[k][q] = 0.f;
+        hp[k][0] = __builtin_nanf("");  // lanes past H score nothing
+        if (h < H) {
+            const float4 a = *reinterpret_cast<const float4 *>(hyp8 + 8 * (size_t)h);
+            hp[k][0] = a.x; hp[k][1] = a.y; hp[k][2] = a.z; hp[k][3] = a.w;
+            if (MODEL == 1) {
+                const float4 b = *reinterpret_cast<const float4 *>(hyp8 + 8 * (size_t)h + 4);
+                const float2 bd = band[h];
+                hp[k][4] = b.x; hp[k][5] = b.y; hp[k][6] = bd.x; hp[k][7] = bd.y;
+            }
         }
     }
     __syncthreads();
-    uint32_t c = 0;
-    for (uint32_t j = 0; j < m4; j += 4) {
-        const float4 p0 = lp[j], p1 = lp[j + 1], p2 = lp[j + 2], p3 = lp[j + 3];  // broadcast reads
-        if (MODEL == 0) {
-            c += plane_inlier(p0.x, p0.y, p0.z, h0, h1, h2, h3, tau) ? 1u : 0u;
-            c += plane_inlier(p1.x, p1.y, p1.z, h0, h1, h2, h3, tau) ? 1u : 0u;
-            c += plane_inlier(p2.x, p2.y, p2.z, h0, h1, h2, h3, tau) ? 1u : 0u;
-            c += plane_inlier(p3.x, p3.y, p3.z, h0, h1, h2, h3, tau) ? 1u : 0u;
-        } else {
-            c += cyl_inlier(p0.x, p0.y, p0.z, h0, h1, h2, h3, h4, h5, lo2, hi2) ? 1u : 0u;
-            c += cyl_inlier(p1.x, p1.y, p1.z, h0, h1, h2, h3, h4, h5, lo2, hi2) ? 1u : 0u;
-            c += cyl_inlier(p2.x, p2.y, p2.z, h0, h1, h2, h3, h4, h5, lo2, hi2) ? 1u : 0u;
-            c += cyl_inlier(p3.x, p3.y, p3.z, h0, h1, h2, h3, h4, h5, lo2, hi2) ? 1u : 0u;
+    for (uint32_t gi = 0; gi < groups; ++gi) {
+        const float4 X = lp[gi][0], Y = lp[gi][1], Z = lp[gi][2];  // broadcast reads: 4 points
+        const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+#pragma unroll
+        for (int k = 0; k < kScHPL; ++k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (MODEL == 0)
+                    c[k] += plane_inlier(xs[q], ys[q], zs[q], hp[k][0], hp[k][1], hp[k][2], hp[k][3], tau) ? 1u : 0u;
+                else
+                    c[k] += cyl_inlier(xs[q], ys[q], zs[q], hp[k][0], hp[k][1], hp[k][2], hp[k][3], hp[k][4], hp[k][5],
+                                       hp[k][6], hp[k][7]) ? 1u : 0u;
+            }
         }
     }
-    if (h < H && c) atomicAdd(&counts[h], (int32_t)c);
+#pragma unroll
+    for (int k = 0; k < kScHPL; ++k) {
+        const uint32_t h = blockIdx.y * kScHC + k * kScThreads + threadIdx.x;
+        if (h < H && c[k]) atomicAdd(&counts[h], (int32_t)c[k]);
+    }
 }
 
 // arg-max over the hypothesis counts (largest count, lowest index on ties)
