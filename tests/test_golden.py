@@ -1,0 +1,77 @@
+"""Committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py
+from the build's own CPU restatement -- the reference ships none: parity unpinned).
+
+CPU: the oracle must still reproduce them (drift lock).
+GPU: the HIP path against the same files, no oracle .so involved.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def ang(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    s = np.linalg.norm(np.cross(a, b), axis=-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+    return np.arcsin(np.clip(s, 0, 1))
+
+
+def test_fixtures_present():
+    assert len(GOLD) >= 4
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_oracle_reproduces_golden(oc, path):
+    g = np.load(path)
+    b, r, leaf, wf = g["params"]
+    xyz = g["xyz"]
+    keep = oc.crop_box(xyz, b)
+    assert np.array_equal(keep, g["crop_rows"])
+    nrm, cnt = oc.normals(xyz[keep], r, oc.F64)
+    assert np.array_equal(cnt, g["neighbor_counts"])
+    assert np.array_equal(oc.finite_normals(nrm), g["valid_rows"])
+    for mode, tag in ((oc.F64, "f64"), (oc.F32_FAITHFUL, "f32")):
+        res = oc.process_frame(xyz, b, r, leaf, wf, mode)
+        # libm (atan2f/cosf/exp) may differ in the last bit across glibc builds: compare to 1e-6, not bitwise
+        assert np.allclose(res["normals"], g["normals_" + tag], rtol=1e-5, atol=1e-6, equal_nan=True)
+        assert np.allclose(res["M"], g["M_" + tag], rtol=1e-6)
+        assert np.allclose(res["evals"][1:], g["evals_" + tag][1:], rtol=1e-6)
+    cen, key, vcnt, _ = oc.voxel_grid(xyz[keep][g["valid_rows"]], leaf, oc.F64)
+    assert np.array_equal(key, g["voxel_keys"]) and np.array_equal(vcnt, g["voxel_counts"])
+    assert np.allclose(cen, g["voxel_centroids"], atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_gpu_reproduces_golden(gm, path):
+    from geometric_mapping_amd import _lib
+    g = np.load(path)
+    b, r, leaf, wf = g["params"]
+    xyz = g["xyz"]
+    with gm.GeometricMapping(boxFilterBound=b, voxelGridLeafSize=leaf, neighborRadius=r, weightingFactor=wf,
+                             flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_KEEP_COUNTS) as c:
+        res = c.process_frame(xyz)
+        cloud, rows = c.cropped_cloud()
+        nrm = c.normals()
+        cnt = c.neighbor_counts()
+        cen, vcnt = c.voxel_centroids()
+    valid_rows = g["crop_rows"][g["valid_rows"]]
+    assert res["n_cropped"] == len(g["crop_rows"]) and res["n_valid"] == len(valid_rows)
+    assert np.array_equal(rows, valid_rows) and np.array_equal(cloud, xyz[valid_rows])   # bit-exact index work
+    assert np.array_equal(cnt, g["neighbor_counts"])
+    assert np.array_equal(vcnt, g["voxel_counts"]) and np.abs(cen - g["voxel_centroids"]).max() < 2e-6
+    gn = g["normals_f64"]
+    a = ang(nrm[:, :3], gn[:, :3])
+    assert np.quantile(a, 0.99) < 1e-5 and a.max() < 1e-3     # a handful of near-degenerate neighbourhoods in 1k-4k clouds
+    rel = np.abs(nrm[:, 3] - gn[:, 3]) / np.maximum(gn[:, 3], 1e-9)
+    assert np.quantile(rel, 0.99) < 1e-4
+    M = g["M_f64"]
+    assert np.abs(res["scatter"] - M).max() / np.abs(M).max() < 1e-5
+    ev = g["evals_f64"].astype(np.float64)
+    assert abs(res["eigenvalues"][2] - ev[2]) / ev[2] < 1e-5 and abs(res["eigenvalues"][1] - ev[1]) / ev[1] < 1e-5
+    assert abs(res["eigenvalues"][0] - ev[0]) < 1e-5 * ev[2]
+    gap = min(ev[1] - ev[0], ev[2]) / ev[2]
+    assert ang(res["center_axis"], g["evecs_f64"][:, 0]) < 1e-5 / max(gap, 1e-3) * 1.0 + 1e-5

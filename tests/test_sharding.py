@@ -1,0 +1,155 @@
+"""Multi-GPU slab sharding (SURVEY.md par. 8e): host partition with a radius halo,
+per-slab processing, merge of the per-slab records.
+
+CPU tests: the oracle plays the per-slab processor, so the partition / halo / merge
+logic of geometric_mapping_amd/sharding.py is checked without a GPU, including a
+world_size-2 torch.distributed (gloo) all-gather of the records.
+GPU test: the same slabs run one after another on one device through
+gm_set_owned_range, and must reproduce the un-sharded frame.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from geometric_mapping_amd import sharding, synth
+
+B, R, LEAF, WF = 5.0, 0.5, 0.5, 0.2
+
+
+def ang(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    s = np.linalg.norm(np.cross(a, b)) / (np.linalg.norm(a) * np.linalg.norm(b))
+    return float(np.arcsin(min(1.0, s)))
+
+
+def oracle_slab(oc, xyz, rows, own_lo, own_hi):
+    """What one rank computes: crop -> normals over (own + halo) -> keep finite & owned."""
+    sub = xyz[rows]
+    keep = oc.crop_box(sub, B)
+    c1 = sub[keep]
+    nrm, _ = oc.normals(c1, R, oc.F64)
+    x = c1[:, 0]
+    ok = np.isfinite(nrm[:, :3]).all(axis=1) & (x >= np.float32(own_lo)) & (x < np.float32(own_hi))
+    cloud, nv = c1[ok], nrm[ok]
+    _, _, M = oc.local_frame(nv, WF, oc.F64)
+    cen, _, cnt, _ = oc.voxel_grid(cloud, LEAF, oc.F64)
+    sc6 = np.array([M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2]])
+    res = dict(scatter6=sc6, n_in=len(sub), n_cropped=len(c1), n_valid=len(cloud), n_voxels=len(cen))
+    return res, rows[keep][ok], cloud, nv, cen, cnt
+
+
+@pytest.mark.parametrize("n_slabs", [2, 4, 8])
+def test_slabs_reproduce_the_single_shard_result(oc, n_slabs):
+    xyz = synth.tunnel_frame(24000, seed=6, outlier_frac=0.01)
+    full = oc.process_frame(xyz, B, R, LEAF, WF, oc.F64)
+    edges = sharding.slab_edges(xyz, n_slabs, B)
+    assert len(edges) == n_slabs + 1 and edges[0] == -np.inf and edges[-1] == np.inf and np.all(np.diff(edges[1:-1]) > 0)
+    parts = sharding.cut_slabs(xyz, edges, halo=R * 1.01)
+    recs, clouds, normals, vox = [], [], [], []
+    for g in range(n_slabs):
+        res, grow, cloud, nv, cen, cnt = oracle_slab(oc, xyz, parts[g], edges[g], edges[g + 1])
+        recs.append(sharding.pack_record(res))
+        clouds.append((grow, cloud)); normals.append((grow, nv)); vox.append((cen, cnt))
+    # balanced ownership
+    owned = np.array([r[8] for r in recs])
+    assert owned.sum() == full["n_valid"] and owned.max() < 1.25 * owned.mean() + 50
+    # merged cloud / normals: identical to the single-shard outputs, same order
+    mc, rows = sharding.merge_clouds(clouds)
+    mn, _ = sharding.merge_clouds(normals)
+    assert np.array_equal(mc, full["xyz"]) and np.all(np.diff(rows) > 0)
+    assert np.array_equal(mn, full["normals"])               # halo makes every owned neighbourhood complete
+    # merged scatter matrix -> same frame
+    sc, counts = sharding.unpack_records(np.concatenate(recs))
+    m6 = sharding.merge_scatter(sc)
+    M = full["M"]
+    ref6 = np.array([M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2]])
+    assert np.abs(m6 - ref6).max() / np.abs(ref6).max() < 1e-13
+    # voxels split by a slab edge are re-joined by count-weighted means
+    mv, mcnt = sharding.merge_voxels(vox, LEAF)
+    assert len(mv) == full["n_voxels"] and mcnt.sum() == full["n_valid"]
+    assert np.abs(mv - full["voxels"]).max() < 1e-6
+
+
+def test_edges_are_float32_and_degenerate_inputs(oc):
+    xyz = synth.tunnel_frame(5000, seed=1)
+    e = sharding.slab_edges(xyz, 4, B)
+    assert all(float(np.float32(v)) == v for v in e[1:-1])
+    e0 = sharding.slab_edges(np.zeros((0, 3), np.float32), 3, B)
+    assert len(e0) == 4
+    parts = sharding.cut_slabs(np.zeros((0, 3), np.float32), e0, 0.5)
+    assert all(len(p) == 0 for p in parts)
+
+
+def _gloo_worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle_c as oc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    xyz = synth.tunnel_frame(12000, seed=3, outlier_frac=0.01)
+    edges = sharding.slab_edges(xyz, world, B)
+    rows = sharding.cut_slabs(xyz, edges, halo=R * 1.01)[rank]
+    res, *_ = oracle_slab(oc, xyz, rows, edges[rank], edges[rank + 1])
+    rec = torch.from_numpy(sharding.pack_record(res))
+    gathered = torch.zeros(world * sharding.RECORD_LEN, dtype=torch.float64)
+    dist.all_gather_into_tensor(gathered, rec)                # the data-path collective of slab mode
+    sc, counts = sharding.unpack_records(gathered.numpy())
+    m6 = sharding.merge_scatter(sc)
+    np.save(os.path.join(tmp, f"m6_{rank}.npy"), m6)
+    np.save(os.path.join(tmp, f"cnt_{rank}.npy"), counts)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_allgather_merge(oc, tmp_path):
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "m6_0.npy"), np.load(tmp_path / "m6_1.npy")
+    assert np.array_equal(a, b)                               # every rank holds the same merged matrix
+    xyz = synth.tunnel_frame(12000, seed=3, outlier_frac=0.01)
+    full = oc.process_frame(xyz, B, R, LEAF, WF, oc.F64)
+    M = full["M"]
+    ref6 = np.array([M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2]])
+    assert np.abs(a - ref6).max() / np.abs(ref6).max() < 1e-13
+    cnt = np.load(tmp_path / "cnt_0.npy")
+    assert cnt[:, 2].sum() == full["n_valid"]
+    w, V = oc.eig3(np.array([[a[0], a[1], a[2]], [a[1], a[3], a[4]], [a[2], a[4], a[5]]]))
+    assert ang(V[:, 0], full["evecs"][:, 0]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_slabs", [2, 4])
+def test_gpu_slabs_reproduce_the_unsharded_frame(gm, n_slabs):
+    xyz = synth.tunnel_frame(60000, seed=6, outlier_frac=0.01)
+    with gm.GeometricMapping() as c:
+        full = c.process_frame(xyz)
+        fcloud, frows = c.cropped_cloud()
+        fn = c.normals()
+        fcen, fcnt = c.voxel_centroids()
+    edges = sharding.slab_edges(xyz, n_slabs, B)
+    parts = sharding.cut_slabs(xyz, edges, halo=R * 1.01)
+    recs, clouds, normals, vox = [], [], [], []
+    for g in range(n_slabs):                                  # one context per "rank", run in turn on this GPU
+        with gm.GeometricMapping() as c:
+            c.set_owned_range(edges[g], edges[g + 1])
+            res = c.process_frame(xyz[parts[g]])
+            cloud, rows = c.cropped_cloud()
+            recs.append(sharding.pack_record(res))
+            clouds.append((parts[g][rows], cloud)); normals.append((parts[g][rows], c.normals()))
+            vox.append(c.voxel_centroids())
+    mc, rows = sharding.merge_clouds(clouds)
+    mn, _ = sharding.merge_clouds(normals)
+    assert np.array_equal(rows, frows) and np.array_equal(mc, fcloud)
+    # same neighbour sets, but a slab's points sit in a different order inside a grid cell: fp32 sums may differ
+    assert np.abs(mn - fn).max() < 2e-6
+    sc, _ = sharding.unpack_records(np.concatenate(recs))
+    m6 = sharding.merge_scatter(sc)
+    assert np.abs(m6 - full["scatter6"]).max() / np.abs(full["scatter6"]).max() < 1e-6
+    ev, V = gm.solve_local_frame(m6)
+    assert ang(V[:, 0], full["center_axis"]) < 1e-5
+    mv, mcnt = sharding.merge_voxels(vox, LEAF)
+    assert np.array_equal(mcnt, fcnt) and np.abs(mv - fcen).max() < 1e-6
