@@ -66,8 +66,10 @@ def test_gpu_reproduces_golden(gm, path):
     gn = g["normals_f64"]
     a = ang(nrm[:, :3], gn[:, :3])
     assert np.quantile(a, 0.99) < 1e-5 and a.max() < 1e-3     # a handful of near-degenerate neighbourhoods in 1k-4k clouds
-    rel = np.abs(nrm[:, 3] - gn[:, 3]) / np.maximum(gn[:, 3], 1e-9)
-    assert np.quantile(rel, 0.99) < 1e-4
+    # curvature: relative where it is well-posed; 3-5-point neighbourhoods are (nearly) rank deficient,
+    # their lambda0 is rounding noise in any precision -> absolute floor
+    err = np.abs(nrm[:, 3] - gn[:, 3]) - 1e-4 * gn[:, 3]
+    assert np.quantile(err, 0.99) < 2e-6
     M = g["M_f64"]
     assert np.abs(res["scatter"] - M).max() / np.abs(M).max() < 1e-5
     ev = g["evals_f64"].astype(np.float64)
