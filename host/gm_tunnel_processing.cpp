@@ -1,0 +1,168 @@
+// gm_tunnel_processing.cpp -- see gm_tunnel_processing.hpp.  Plain C++11; links libgm_hip.so.
+#include "gm_tunnel_processing.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace gm_host {
+
+void Processor::check(gm_status s, const char *what)
+{
+    if (s != GM_OK) throw Error(s, std::string(what) + ": " + gm_status_string(s) + ": " + gm_last_error(ctx_));
+}
+
+Processor::Processor(double b, double leaf, double r, double wf, int device, unsigned flags) : ctx_(0)
+{
+    gm_config cfg;
+    gm_default_config(&cfg);
+    cfg.boxFilterBound = b; cfg.voxelGridLeafSize = leaf; cfg.neighborRadius = r; cfg.weightingFactor = wf;
+    cfg.device = device; cfg.flags = flags;
+    gm_status s = gm_create(&cfg, &ctx_);
+    if (s != GM_OK) throw Error(s, std::string("gm_create: ") + gm_last_error(0));
+}
+
+Processor::~Processor() { gm_destroy(ctx_); }
+
+PointCloud Processor::chopCloud(const double &bound, const PointCloud &cloud)
+{
+    gm_cloud c = {cloud.empty() ? 0 : &cloud[0], (uint32_t)cloud.size(), 16, 0, 4, 8, 0};
+    PointCloud out(cloud.size() ? cloud.size() : 1);
+    uint32_t n = 0;
+    check(gm_chop_cloud(ctx_, &c, bound, &out[0].x, (uint32_t)out.size(), &n), "chopCloud");
+    out.resize(n);
+    return out;
+}
+
+NormalCloud Processor::getNormals(const double &radius, PointCloud &cloud)
+{
+    const size_t n0 = cloud.size();
+    std::vector<float> xyz(3 * (n0 ? n0 : 1));
+    for (size_t i = 0; i < n0; ++i) { xyz[3 * i] = cloud[i].x; xyz[3 * i + 1] = cloud[i].y; xyz[3 * i + 2] = cloud[i].z; }
+    PointCloud oc(n0 ? n0 : 1);
+    NormalCloud on(n0 ? n0 : 1);
+    uint32_t n = 0;
+    check(gm_get_normals_stage(ctx_, &xyz[0], (uint32_t)n0, radius, &oc[0].x, &on[0].normal[0], (uint32_t)oc.size(), &n),
+          "getNormals");
+    oc.resize(n); on.resize(n);
+    cloud.swap(oc);  // ExtractIndices::filter(*cloud): the caller's cloud is compacted in place
+    return on;
+}
+
+void Processor::getLocalFrame(const int &cloudSize, const double &wf, const NormalCloud &nrm, Vector3f &vals, Matrix3f &vecs)
+{
+    if (cloudSize < 0 || (size_t)cloudSize > nrm.size())
+        throw std::out_of_range("getLocalFrame: cloudSize exceeds the normals cloud");  // the reference's .at() (:106)
+    check(gm_get_local_frame(ctx_, nrm.empty() ? 0 : &nrm[0].normal[0], (uint32_t)cloudSize, wf, vals.v, vecs.m, 0),
+          "getLocalFrame");
+}
+
+PointCloud Processor::voxelGrid(const double &leaf, const PointCloud &cloud)
+{
+    const size_t n0 = cloud.size();
+    std::vector<float> xyz(3 * (n0 ? n0 : 1));
+    for (size_t i = 0; i < n0; ++i) { xyz[3 * i] = cloud[i].x; xyz[3 * i + 1] = cloud[i].y; xyz[3 * i + 2] = cloud[i].z; }
+    PointCloud out(n0 ? n0 : 1);
+    uint32_t n = 0, fl = 0;
+    check(gm_voxel_grid(ctx_, &xyz[0], (uint32_t)n0, leaf, &out[0].x, (uint32_t)out.size(), &n, &fl), "voxelGrid");
+    out.resize(n);
+    return out;
+}
+
+std::vector<int> Processor::nearest(const PointCloud &cloud, const PointCloud &queries)
+{
+    std::vector<float> a(3 * (cloud.size() ? cloud.size() : 1)), q(3 * (queries.size() ? queries.size() : 1));
+    for (size_t i = 0; i < cloud.size(); ++i) { a[3 * i] = cloud[i].x; a[3 * i + 1] = cloud[i].y; a[3 * i + 2] = cloud[i].z; }
+    for (size_t i = 0; i < queries.size(); ++i) { q[3 * i] = queries[i].x; q[3 * i + 1] = queries[i].y; q[3 * i + 2] = queries[i].z; }
+    std::vector<int> idx(queries.size() ? queries.size() : 1);
+    check(gm_nearest(ctx_, &a[0], (uint32_t)cloud.size(), &q[0], (uint32_t)queries.size(), &idx[0]), "nearest");
+    idx.resize(queries.size());
+    return idx;
+}
+
+gm_frame_result Processor::processFrame(const void *rows, unsigned n, unsigned step, unsigned ox, unsigned oy, unsigned oz,
+                                        bool bigendian)
+{
+    gm_cloud c = {rows, n, step, ox, oy, oz, bigendian ? GM_CLOUD_BIGENDIAN : 0u};
+    gm_frame_result r;
+    check(gm_process_frame(ctx_, &c, &r), "processFrame");
+    return r;
+}
+
+PointCloud Processor::choppedCloud()
+{
+    uint32_t n = 0;
+    gm_status s = gm_get_cropped_xyz(ctx_, 0, 0, 0, &n);
+    if (s != GM_OK && s != GM_ERR_CAPACITY) check(s, "choppedCloud");
+    PointCloud out(n ? n : 1);
+    check(gm_get_cropped_xyz(ctx_, 0, &out[0].x, (uint32_t)out.size(), &n), "choppedCloud");
+    out.resize(n);
+    return out;
+}
+
+NormalCloud Processor::normals()
+{
+    uint32_t n = 0;
+    gm_status s = gm_get_normals(ctx_, 0, 0, 0, &n);
+    if (s != GM_OK && s != GM_ERR_CAPACITY) check(s, "normals");
+    NormalCloud out(n ? n : 1);
+    check(gm_get_normals(ctx_, 0, &out[0].normal[0], (uint32_t)out.size(), &n), "normals");
+    out.resize(n);
+    return out;
+}
+
+PointCloud Processor::voxelCentroids()
+{
+    uint32_t n = 0;
+    gm_status s = gm_get_voxel_centroids(ctx_, 0, 0, 0, &n);
+    if (s != GM_OK && s != GM_ERR_CAPACITY) check(s, "voxelCentroids");
+    PointCloud out(n ? n : 1);
+    check(gm_get_voxel_centroids(ctx_, 0, &out[0].x, (uint32_t)out.size(), &n), "voxelCentroids");
+    out.resize(n);
+    return out;
+}
+
+// ---- marker formatting: src/tunnel_processing.cpp:161-205, 225-256, 260-300 ----
+
+Marker Processor::rvizArrow(const Vector3f &start, const Vector3f &end, const Vector3f &scale, const Vector4f &color,
+                            const std::string &ns, const int &id, const std::string &frame)
+{
+    Marker m;
+    m.frame_id = frame;      // :174 (stamp = ros::Time::now() and seq = 0 are set by the ROS shim)
+    m.ns = ns; m.id = id;    // :177-178
+    m.type = MARKER_ARROW; m.action = MARKER_ADD;  // :179-180
+    for (int k = 0; k < 3; ++k) { m.points[0][k] = start(k); m.points[1][k] = end(k); m.scale[k] = scale(k); }
+    m.color_a = color(0); m.color_r = color(1); m.color_g = color(2); m.color_b = color(3);  // :199-202: A,R,G,B
+    return m;
+}
+
+MarkerArray Processor::rvizNormals(const double &leafSize, const PointCloud &cloud, const NormalCloud &nrm)
+{
+    const PointCloud vox = voxelGrid(leafSize, cloud);        // :217-220
+    const std::vector<int> idx = nearest(cloud, vox);         // :239 (searched in the compacted cloud)
+    MarkerArray out(vox.size());
+    const Vector3f scale = {{0.025f, 0.075f, 0.0625f}};       // :230
+    const Vector4f color = {{1, 0, 0, 1}};                    // :231
+    for (size_t i = 0; i < vox.size(); ++i) {
+        const Vector3f s = {{vox[i].x, vox[i].y, vox[i].z}};
+        const Normal &nn = nrm.at((size_t)idx[i]);
+        const Vector3f e = {{nn.normal[0], nn.normal[1], nn.normal[2]}};   // :247-249: the arrow END is the normal itself
+        out[i] = rvizArrow(s, e, scale, color, "normals", (int)i);
+    }
+    return out;
+}
+
+MarkerArray Processor::rvizEigens(const Vector3f &vals, const Matrix3f &vecs)
+{
+    MarkerArray out(3);
+    const float nrm = std::sqrt(vals(0) * vals(0) + vals(1) * vals(1) + vals(2) * vals(2));
+    for (int i = 0; i < 3; ++i) {
+        const float e = (1.0f / nrm) * std::fabs(vals(i));    // :265
+        const Vector3f scale = {{(float)(0.1 - (0.05 * e)), (float)(0.3 - (0.15 * e)), (float)(0.25 - (0.125 * e))}};  // :274-278
+        const Vector4f color = {{1.0f, i == 0 ? 1.0f : 0.0f, i == 1 ? 1.0f : 0.0f, i == 2 ? 1.0f : 0.0f}};          // :280-287
+        const Vector3f zero = {{0, 0, 0}};
+        out[i] = rvizArrow(zero, vecs.col(i), scale, color, "eigenBasis", i);   // :289-296
+    }
+    return out;
+}
+
+}  // namespace gm_host

@@ -1,0 +1,95 @@
+// gm_tunnel_processing.hpp -- ROS-free C++ host mirror of the reference's
+// processing + marker functions, implemented on the C ABI of libgm_hip.so.
+//
+// Same names, argument order and meaning as
+//   /root/reference include/geometric_mapping/tunnel_processing.hpp:38-54,66-85
+// with PCL / Eigen / ROS message types replaced by plain structs of identical
+// layout, so a catkin node can convert at its edges (ros/geometric_mapping_node.cpp)
+// and everything below compiles with a bare C++11 compiler -- no HIP headers.
+// Unlike the reference nothing here is heap-allocated-and-leaked
+// (src/tunnel_processing.cpp:131,135,171,225,261): results are values.
+#ifndef GM_TUNNEL_PROCESSING_HPP
+#define GM_TUNNEL_PROCESSING_HPP
+
+#include <array>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../include/gm_hip.h"
+
+namespace gm_host {
+
+struct PointXYZ { float x, y, z, pad; };                 // = pcl::PointXYZ (16 B)
+struct Normal { float normal[3]; float curvature; };      // meaningful fields of pcl::Normal
+typedef std::vector<PointXYZ> PointCloud;
+typedef std::vector<Normal> NormalCloud;
+
+struct Vector3f { float v[3]; float operator()(int i) const { return v[i]; } float &operator()(int i) { return v[i]; } };
+struct Vector4f { float v[4]; float operator()(int i) const { return v[i]; } };
+struct Matrix3f {                                         // column-major, like Eigen::Matrix3f
+    float m[9];
+    float operator()(int r, int c) const { return m[3 * c + r]; }
+    Vector3f col(int c) const { Vector3f o = {{m[3 * c], m[3 * c + 1], m[3 * c + 2]}}; return o; }
+};
+
+// visualization_msgs/Marker fields the reference fills (src/tunnel_processing.cpp:161-205)
+struct Marker {
+    std::string frame_id, ns;
+    int id, type, action;
+    double points[2][3];
+    double scale[3];
+    float color_a, color_r, color_g, color_b;
+};
+typedef std::vector<Marker> MarkerArray;
+enum { MARKER_ARROW = 0, MARKER_ADD = 0 };                // visualization_msgs::Marker::ARROW / ADD
+
+class Error : public std::runtime_error {
+public:
+    Error(gm_status s, const std::string &what) : std::runtime_error(what), status(s) {}
+    gm_status status;
+};
+
+// Owns the gm_ctx; the reference's globals `params` + per-call PCL objects collapse into this.
+class Processor {
+public:
+    // names/defaults: include/geometric_mapping/paramHandler.hpp:26-29, launch/mapping.launch:7-10
+    Processor(double boxFilterBound = 5.0, double voxelGridLeafSize = 0.5, double neighborRadius = 0.5,
+              double weightingFactor = 0.2, int device = 0, unsigned flags = GM_CFG_DEFAULT);
+    ~Processor();
+
+    // ---- tunnel_processing.hpp:38-54 ----
+    PointCloud chopCloud(const double &bound, const PointCloud &cloud);
+    // compacts `cloud` in place (NaN-normal rows removed), like the reference (:81-85)
+    NormalCloud getNormals(const double &neighborRadius, PointCloud &cloud);
+    void getLocalFrame(const int &cloudSize, const double &weightingFactor, const NormalCloud &cloud_normals,
+                       Vector3f &eigenVals, Matrix3f &eigenVecs);
+    // the pcl::VoxelGrid half of rvizNormals (:214-220)
+    PointCloud voxelGrid(const double &leafSize, const PointCloud &cloud);
+    // kdtree->nearestKSearch(q, 1) (:237-239)
+    std::vector<int> nearest(const PointCloud &cloud, const PointCloud &queries);
+
+    // ---- the whole callback (src/geometric_mapping.cpp:55-92) in one device pass ----
+    gm_frame_result processFrame(const void *rows, unsigned n_points, unsigned point_step, unsigned off_x, unsigned off_y,
+                                 unsigned off_z, bool bigendian = false);
+    PointCloud choppedCloud();        // /choppedCloud of the last frame
+    NormalCloud normals();
+    PointCloud voxelCentroids();
+
+    // ---- tunnel_processing.hpp:66-85 (pure host formatting, no device work) ----
+    static Marker rvizArrow(const Vector3f &start, const Vector3f &end, const Vector3f &scale, const Vector4f &color,
+                            const std::string &ns, const int &id = 0, const std::string &frame = "/velodyne");
+    MarkerArray rvizNormals(const double &leafSize, const PointCloud &cloud, const NormalCloud &normals);
+    static MarkerArray rvizEigens(const Vector3f &eigenVals, const Matrix3f &eigenVecs);
+
+    gm_ctx *ctx() { return ctx_; }
+
+private:
+    void check(gm_status s, const char *what);
+    gm_ctx *ctx_;
+    Processor(const Processor &);
+    Processor &operator=(const Processor &);
+};
+
+}  // namespace gm_host
+#endif

@@ -1,0 +1,164 @@
+// geometric_mapping_node.cpp -- catkin/ROS host for libgm_hip.so.
+//
+// Keeps the reference node's surface exactly (so launch/mapping.launch and
+// rviz_config/mapping.rviz of the reference work unchanged):
+//   node name  geometric_mapping_node                       (src/geometric_mapping.cpp:130)
+//   sub        "input"            sensor_msgs/PointCloud2, queue 1       (:146)
+//   pub        "cloudOutput"      sensor_msgs/PointCloud2, queue 10, if displayCloud      (:149-151)
+//   pub        "normalsOutput"    visualization_msgs/MarkerArray, queue 10, if displayNormals    (:154-156)
+//   pub        "eigenBasisOutput" visualization_msgs/MarkerArray, queue 10, if displayCenterAxis (:159-161)
+//   params     boxFilterBound voxelGridLeafSize neighborRadius weightingFactor
+//              displayCloud displayNormals displayCenterAxis usePCLViz   (src/paramHandler.cpp:12-66)
+// and replaces the PCL/Eigen arithmetic of cloud_cb (:48-125) with ONE call into
+// the C ABI (gm_process_frame reads the PointCloud2 rows directly: no pcl::fromROSMsg).
+//
+// NOT COMPILED in this repository's CI: ROS is absent from the build image
+// (SURVEY.md Appendix B).  Build it in a catkin workspace with ros/CMakeLists.txt.
+// Deliberate differences from the reference, all on non-default paths:
+//   * usePCLViz is accepted and ignored with a warning (the reference stores the
+//     address of a block-local PCLVisualizer: dangling, src/geometric_mapping.cpp:140-143);
+//   * nothing is heap-allocated per frame (the reference leaks 5 objects per callback);
+//   * 1-NN for /surfaceNormals searches the compacted cloud (the reference's kd-tree
+//     still indexes the pre-compaction cloud, src/tunnel_processing.cpp:65,85,239).
+#include <ros/ros.h>
+#include <sensor_msgs/PointCloud2.h>
+#include <sensor_msgs/PointField.h>
+#include <visualization_msgs/MarkerArray.h>
+
+#include <cstring>
+#include <memory>
+
+#include "../host/gm_tunnel_processing.hpp"
+
+namespace {
+
+struct Parameters {  // mirrors class Parameters, include/geometric_mapping/paramHandler.hpp:9-37
+    double boxFilterBound = 5.0, leafSize = .1, neighborRadius = .03, weightingFactor = .2;
+    bool rvizCloud = true, rvizNormals = true, rvizCenterAxis = true, pclviz = false;
+    explicit Parameters(ros::NodeHandle &node)
+    {
+        // global names, read once (src/paramHandler.cpp:13-65); log text kept
+        if (node.getParam("boxFilterBound", boxFilterBound)) ROS_INFO("boxFilterBound set to: \t %f", boxFilterBound);
+        else ROS_INFO("ERROR: boxFilterBound set to default");
+        if (node.getParam("voxelGridLeafSize", leafSize)) ROS_INFO("voxelGridLeafSize set to: \t %f", leafSize);
+        else ROS_INFO("ERROR: voxelGridLeafSize set to default");
+        if (node.getParam("neighborRadius", neighborRadius)) ROS_INFO("neighborRadius set to: \t %f", neighborRadius);
+        else ROS_INFO("ERROR: neighborRadius set to default");
+        if (node.getParam("weightingFactor", weightingFactor)) ROS_INFO("weightingFactor set to: \t %f", weightingFactor);
+        else ROS_INFO("ERROR: weightingFactor set to default");
+        node.getParam("displayCloud", rvizCloud);
+        node.getParam("displayNormals", rvizNormals);
+        node.getParam("displayCenterAxis", rvizCenterAxis);
+        node.getParam("usePCLViz", pclviz);
+    }
+};
+
+std::unique_ptr<Parameters> params;
+std::unique_ptr<gm_host::Processor> proc;
+ros::Publisher cloudPub, normalsPub, centerAxisPub;
+
+bool find_xyz(const sensor_msgs::PointCloud2 &m, unsigned &ox, unsigned &oy, unsigned &oz)
+{
+    bool fx = false, fy = false, fz = false;
+    for (const sensor_msgs::PointField &f : m.fields) {
+        if (f.datatype != sensor_msgs::PointField::FLOAT32) continue;
+        if (f.name == "x") { ox = f.offset; fx = true; }
+        else if (f.name == "y") { oy = f.offset; fy = true; }
+        else if (f.name == "z") { oz = f.offset; fz = true; }
+    }
+    return fx && fy && fz;
+}
+
+visualization_msgs::MarkerArray to_ros(const gm_host::MarkerArray &in)
+{
+    visualization_msgs::MarkerArray out;
+    out.markers.resize(in.size());
+    for (size_t i = 0; i < in.size(); ++i) {
+        visualization_msgs::Marker &m = out.markers[i];
+        const gm_host::Marker &s = in[i];
+        m.header.frame_id = s.frame_id;
+        m.header.stamp = ros::Time::now();  // src/tunnel_processing.cpp:175 (not the input stamp)
+        m.header.seq = 0;
+        m.ns = s.ns; m.id = s.id;
+        m.type = visualization_msgs::Marker::ARROW;
+        m.action = visualization_msgs::Marker::ADD;
+        m.points.resize(2);
+        for (int k = 0; k < 2; ++k) { m.points[k].x = s.points[k][0]; m.points[k].y = s.points[k][1]; m.points[k].z = s.points[k][2]; }
+        m.scale.x = s.scale[0]; m.scale.y = s.scale[1]; m.scale.z = s.scale[2];
+        m.color.a = s.color_a; m.color.r = s.color_r; m.color.g = s.color_g; m.color.b = s.color_b;
+    }
+    return out;
+}
+
+void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input)
+{
+    ROS_INFO("Callback started...");
+    unsigned ox = 0, oy = 4, oz = 8;
+    if (!find_xyz(*input, ox, oy, oz)) { ROS_ERROR("input cloud has no float32 x/y/z fields"); return; }
+    const unsigned n = input->width * input->height;
+    gm_frame_result r;
+    try {
+        // fromROSMsg + chopCloud + getNormals + VoxelGrid + getLocalFrame: one device pass (:55-92)
+        r = proc->processFrame(n ? &input->data[0] : nullptr, n, input->point_step, ox, oy, oz, input->is_bigendian);
+    } catch (const gm_host::Error &e) {
+        ROS_ERROR("libgm_hip: %s", e.what());
+        return;
+    }
+    ROS_INFO("Box filter applied...");
+    ROS_INFO("Surface normals found...");
+    gm_host::Vector3f vals = {{r.eigenvalues[0], r.eigenvalues[1], r.eigenvalues[2]}};
+    gm_host::Matrix3f vecs;
+    std::memcpy(vecs.m, r.eigenvectors, sizeof(vecs.m));
+    ROS_INFO("Center Axis found...");
+
+    if (params->rvizCloud) {  // :100-107, xyz-only PointCloud2 as pcl::toROSMsg lays it out (16-byte points)
+        const gm_host::PointCloud cloud = proc->choppedCloud();
+        sensor_msgs::PointCloud2 out;
+        out.header = input->header;
+        out.height = 1; out.width = (uint32_t)cloud.size();
+        out.is_bigendian = false; out.is_dense = true;
+        out.point_step = 16; out.row_step = 16 * out.width;
+        out.fields.resize(3);
+        const char *names[3] = {"x", "y", "z"};
+        for (int k = 0; k < 3; ++k) {
+            out.fields[k].name = names[k]; out.fields[k].offset = 4 * k;
+            out.fields[k].datatype = sensor_msgs::PointField::FLOAT32; out.fields[k].count = 1;
+        }
+        out.data.resize((size_t)out.row_step);
+        if (!cloud.empty()) std::memcpy(&out.data[0], &cloud[0], out.data.size());
+        cloudPub.publish(out);
+    }
+    if (params->rvizNormals) {  // :109-112
+        gm_host::PointCloud cloud = proc->choppedCloud();
+        const gm_host::NormalCloud nrm = proc->normals();
+        normalsPub.publish(to_ros(proc->rvizNormals(params->leafSize, cloud, nrm)));
+    }
+    if (params->rvizCenterAxis)  // :114-117
+        centerAxisPub.publish(to_ros(gm_host::Processor::rvizEigens(vals, vecs)));
+    ROS_INFO("Published...");
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    ros::init(argc, argv, "geometric_mapping_node");
+    ros::NodeHandle node;
+    params.reset(new Parameters(node));
+    ROS_INFO("Launched geometric_mapping_node...");
+    if (params->pclviz) ROS_WARN("usePCLViz is ignored by the MI355X host (no PCL in this build)");
+    try {
+        proc.reset(new gm_host::Processor(params->boxFilterBound, params->leafSize, params->neighborRadius,
+                                          params->weightingFactor));
+    } catch (const gm_host::Error &e) {
+        ROS_FATAL("libgm_hip: %s", e.what());
+        return 1;
+    }
+    ros::Subscriber sub = node.subscribe("input", 1, cloud_cb);
+    if (params->rvizCloud) cloudPub = node.advertise<sensor_msgs::PointCloud2>("cloudOutput", 10);
+    if (params->rvizNormals) normalsPub = node.advertise<visualization_msgs::MarkerArray>("normalsOutput", 10);
+    if (params->rvizCenterAxis) centerAxisPub = node.advertise<visualization_msgs::MarkerArray>("eigenBasisOutput", 10);
+    ros::spin();
+    proc.reset();
+    return 0;
+}
