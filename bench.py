@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--radius", type=float, default=None, help="default: fixed-k 0.5*sqrt(50000/points)")
     ap.add_argument("--mode", choices=("frames", "slab"), default="frames")
     ap.add_argument("--slots", type=int, default=2, help="frames in flight per GPU (HIP streams)")
-    ap.add_argument("--ransac", type=int, default=1, help="1: include the cylinder RANSAC model (extension) when built")
+    ap.add_argument("--ransac", type=int, default=1,
+                    help="1: the step includes ONE RANSAC model (cylinder, H=1024: BASELINE configs[1]); 0: reference-faithful path only")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra reference-faithful / host-input legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
@@ -67,12 +69,12 @@ def cpu_baseline(points, radius, threads):
     t0 = time.perf_counter()
     oc.process_frame(xyz, 5.0, radius, 0.5, 0.2, oc.F32_FAITHFUL, nthreads=ncores, want_outputs=False)
     dt_all = time.perf_counter() - t0
-    # single thread = how the reference actually executes (ros::spin, non-OMP NormalEstimation);
-    # bounded: one fifth of the frame at the same density (same radius => same k)
+    # single thread = how the reference actually executes (ros::spin, non-OMP NormalEstimation).
+    # Bounded sample: one fifth of the frame; density drops 5x, so r*sqrt(5) keeps k (~256) and
+    # with it the work per point.
     sub = xyz[: points // 5]
-    r_sub = radius  # k scales with density; keep the work per point comparable by keeping k: r*sqrt(5)
     t0 = time.perf_counter()
-    oc.process_frame(sub, 5.0, r_sub * np.sqrt(5.0), 0.5, 0.2, oc.F32_FAITHFUL, nthreads=1, want_outputs=False)
+    oc.process_frame(sub, 5.0, radius * np.sqrt(5.0), 0.5, 0.2, oc.F32_FAITHFUL, nthreads=1, want_outputs=False)
     dt_one = time.perf_counter() - t0
     return {"value": points / dt_all, "unit": "points/s", "cores": int(ncores), "kind": "port",
             "sample": f"1 frame of the same workload ({points} pts, r={radius:.4f}), oracle f32_faithful, OpenMP over query points",
@@ -106,7 +108,7 @@ def main():
     n = args.points
     radius = args.radius if args.radius else synth.fixed_k_radius(n)
     bound, leaf, wf = 5.0, 0.5, 0.2
-    flags = _lib.GM_CFG_DEFAULT
+    flags = _lib.GM_CFG_DEFAULT | _lib.GM_CFG_STAGE_TIMING
     ransac_on = False
     if args.ransac:
         probe = g.load_library()
@@ -138,10 +140,14 @@ def main():
         n_slots = 1
     torch.cuda.synchronize()
 
-    ctx = g.GeometricMapping(boxFilterBound=bound, voxelGridLeafSize=leaf, neighborRadius=radius, weightingFactor=wf,
-                             device=local_rank, flags=flags, n_slots=n_slots, max_points=max(len(d) for d in dev))
-    if own is not None:
-        ctx.set_owned_range(*own)
+    def make_ctx(fl, slots):
+        c = g.GeometricMapping(boxFilterBound=bound, voxelGridLeafSize=leaf, neighborRadius=radius, weightingFactor=wf,
+                               device=local_rank, flags=fl, n_slots=slots, max_points=max(len(d) for d in dev))
+        if own is not None:
+            c.set_owned_range(*own)
+        return c
+
+    ctx = make_ctx(flags, n_slots)
     clouds = [ctx.cloud_from_device(d.data_ptr(), d.shape[0], 16) for d in dev]
 
     def barrier():
@@ -152,55 +158,70 @@ def main():
     rec_dev = torch.zeros(sharding.RECORD_LEN, dtype=torch.float64, device="cuda")
     gathered = torch.zeros(world * sharding.RECORD_LEN, dtype=torch.float64, device="cuda")
 
-    def slab_step(i):
-        res = ctx.process_frame(clouds[0])
+    def slab_step(c):
+        res = c.process_frame(clouds[0])
         rec_dev.copy_(torch.from_numpy(sharding.pack_record(res)))
         dist.all_gather_into_tensor(gathered, rec_dev)
         sc, _ = sharding.unpack_records(gathered.cpu().numpy())
-        ev, V = g.solve_local_frame(sharding.merge_scatter(sc))
-        return res, ev, V
+        g.solve_local_frame(sharding.merge_scatter(sc))
+        return res
 
-    results = []
-
-    def run(steps, collect):
+    def run(c, inputs, steps, slots, results):
         if mode == "slab":
             for i in range(steps):
-                r = slab_step(i)
-                if collect:
-                    results.append(r[0])
+                r = slab_step(c)
+                if results is not None:
+                    results.append(r)
             return
-        # frames: keep n_slots frames in flight on their own HIP streams
+        # frames: keep `slots` frames in flight on their own HIP streams
         inflight = []
         for i in range(steps):
-            slot = i % n_slots
-            if len(inflight) == n_slots:
-                r = ctx.wait_frame(inflight.pop(0))
-                if collect:
+            slot = i % slots
+            if len(inflight) == slots:
+                r = c.wait_frame(inflight.pop(0))
+                if results is not None:
                     results.append(r)
-            ctx.submit_frame(slot, clouds[i % len(clouds)])
+            c.submit_frame(slot, inputs[i % len(inputs)])
             inflight.append(slot)
         while inflight:
-            r = ctx.wait_frame(inflight.pop(0))
-            if collect:
+            r = c.wait_frame(inflight.pop(0))
+            if results is not None:
                 results.append(r)
 
-    run(args.warmup, False)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps, True)
-    if world > 1 and mode == "frames":
-        # fitted records of every rank's last frame to every rank (the node publishes them all)
-        rec_dev.copy_(torch.from_numpy(sharding.pack_record(results[-1])))
-        dist.all_gather_into_tensor(gathered, rec_dev)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def timed(c, inputs, slots):
+        res = []
+        run(c, inputs, args.warmup, slots, None)
+        barrier()
+        t0 = time.perf_counter()
+        run(c, inputs, args.steps, slots, res)
+        if world > 1 and mode == "frames":
+            # fitted records of every rank's last frame to every rank (the node publishes them all)
+            rec_dev.copy_(torch.from_numpy(sharding.pack_record(res[-1])))
+            dist.all_gather_into_tensor(gathered, rec_dev)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, res
 
+    dt, results = timed(ctx, clouds, n_slots)
     total_points = (n * args.steps * world) if mode == "frames" else (n * args.steps)
     value = total_points / dt
+
+    secondary = {}
+    if not args.no_secondary and world == 1:
+        if ransac_on:  # the reference-faithful path alone (no extension work in the step)
+            with make_ctx(_lib.GM_CFG_DEFAULT, n_slots) as c2:
+                dt2, _ = timed(c2, clouds, n_slots)
+            secondary["reference_faithful_path_only"] = {"value": n * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3}
+        # rows handed over as HOST buffers (what the ROS node does): pinned staging + H2D inside the step.
+        # Never the headline value (DESIGN.md par. 7).
+        host_inputs = [ctx._cloud_from_xyz(rows16(f)) for f in frames_host] if mode == "frames" else None
+        if host_inputs:
+            dt3, _ = timed(ctx, host_inputs, n_slots)
+            secondary["host_input_pcie_inclusive"] = {"value": n * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3}
 
     # dominant kernel: the neighbourhood-normals kernel, HIP-event bracketed on the stream
     # it runs on, inside the timed region (gm_frame_result.normals_kernel_ms)
@@ -229,7 +250,7 @@ def main():
             "config": {"workload": f"{n}-pt synthetic tunnel frame (R=2 m, L=12 m, sigma=0.01), rows resident in HBM",
                        "neighborRadius": radius, "k_regime": "fixed-k (~256 neighbours)", "boxFilterBound": bound,
                        "voxelGridLeafSize": leaf, "weightingFactor": wf, "mode": mode, "frames_in_flight": n_slots,
-                       "ransac_model": "cylinder (extension)" if ransac_on else "none (reference-faithful path)",
+                       "ransac_model": "cylinder, H=1024, tau=0.03 (extension)" if ransac_on else "none (reference-faithful path)",
                        "parallelism": f"{mode}x{world}"},
             "roofline": {"kernel": "k_normals", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -239,7 +260,9 @@ def main():
             "whole_path_hbm": {"algorithmic_bytes_per_point": ALGO_BYTES_PER_POINT,
                                "achieved_GBs": value * ALGO_BYTES_PER_POINT / 1e9,
                                "frac_of_spec": value * ALGO_BYTES_PER_POINT / 1e9 / HBM_PEAK_GBS},
+            "stage_ms_last_frame": {k: round(v, 4) for k, v in results[-1]["stage_ms"].items()} if results else {},
         }
+        out.update(secondary)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, radius, args.cpu_threads)
         print(json.dumps(out))
