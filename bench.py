@@ -54,6 +54,9 @@ def parse():
                     help="1: the step includes ONE RANSAC model (cylinder, H=1024: BASELINE configs[1]); 0: reference-faithful path only")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra reference-faithful / host-input legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="nccl (= RCCL) is the real thing; gloo only rehearses the N>1 control flow on a 1-GPU box")
+    ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this device")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
 
@@ -97,10 +100,16 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback to time)")
+    if args.force_device >= 0:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import geometric_mapping_amd as g
     from geometric_mapping_amd import _lib, sharding, synth
@@ -155,8 +164,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    rec_dev = torch.zeros(sharding.RECORD_LEN, dtype=torch.float64, device="cuda")
-    gathered = torch.zeros(world * sharding.RECORD_LEN, dtype=torch.float64, device="cuda")
+    rec_dev = torch.zeros(sharding.RECORD_LEN, dtype=torch.float64, device=coll_dev)
+    gathered = torch.zeros(world * sharding.RECORD_LEN, dtype=torch.float64, device=coll_dev)
 
     def slab_step(c):
         res = c.process_frame(clouds[0])
@@ -201,7 +210,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         return dt, res
@@ -251,7 +260,7 @@ def main():
                        "neighborRadius": radius, "k_regime": "fixed-k (~256 neighbours)", "boxFilterBound": bound,
                        "voxelGridLeafSize": leaf, "weightingFactor": wf, "mode": mode, "frames_in_flight": n_slots,
                        "ransac_model": "cylinder, H=1024, tau=0.03 (extension)" if ransac_on else "none (reference-faithful path)",
-                       "parallelism": f"{mode}x{world}"},
+                       "parallelism": f"{mode}x{world}", "collective_backend": args.dist_backend if world > 1 else None},
             "roofline": {"kernel": "k_normals", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": algo_bytes,
