@@ -45,6 +45,7 @@ struct Slot {
     float4 *vnorm4 = nullptr;     // compacted normals
     uint2 *tiles = nullptr;
     uint32_t tiles_cap = 0;
+    uint2 *row_bounds = nullptr;  // [1024*1024] first / one-past-last sorted position per x-row of the search grid
     uint32_t *blk = nullptr;      // per-block counts / offsets for the compactions
     uint32_t blk_cap = 0;
     SortScratch sort = {};

@@ -48,14 +48,18 @@ __device__ __forceinline__ v2f pk_add_rn(v2f a, v2f b)
 }
 
 constexpr int kNrThreads = 256;
-constexpr int kTileSpan = 2;  // cells of one x-row a tile may span
+constexpr int kSplit = 1;                 // lanes per query: each handles 1/kSplit of the tile's candidates
+constexpr int kTileQ = kWave / kSplit;    // queries per tile
+constexpr int kTileSpan = 3;              // max cell steps (last cell - first cell) inside one tile
 constexpr int kNrWaves = kNrThreads / kWave;
 
 // ---- gather the cropped cloud into cell-sorted order ---------------------------
 __global__ __launch_bounds__(256) void k_gather_sorted(const float4 *__restrict__ crop4,
                                                        const uint32_t *__restrict__ perm,
-                                                       const uint32_t *__restrict__ n_ptr,
-                                                       float4 *__restrict__ spts4)
+                                                       const uint32_t *__restrict__ skeys,
+                                                       const uint32_t *__restrict__ n_ptr, uint32_t nx,
+                                                       float4 *__restrict__ spts4,
+                                                       uint2 *__restrict__ row_bounds /* [ny*nz]: begin, end */)
 {
     const uint32_t n = *n_ptr;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
@@ -63,15 +67,21 @@ __global__ __launch_bounds__(256) void k_gather_sorted(const float4 *__restrict_
         float4 p = crop4[i];
         p.w = __uint_as_float(i);  // cropped index rides in the pad lane
         spts4[s] = p;
+        // first / one-past-last sorted position of every occupied x-row (only occupied rows are ever read)
+        const uint32_t row = skeys[s] / nx;
+        if (s == 0 || skeys[s - 1] / nx != row) row_bounds[row].x = s;
+        if (s + 1 == n || skeys[s + 1] / nx != row) row_bounds[row].y = s + 1;
     }
 }
 
-// ---- tiles: <=64 consecutive sorted points of one group of `span` cells of one x-row ----
-// Bounding the x-extent of a tile bounds its candidate count (sparse rows would
-// otherwise produce tiles spanning tens of cells: a 20x outlier that the whole
-// grid then waits for).
+// ---- tiles: <=64 consecutive sorted points of one x-row spanning <= span+1 cells ----
+// Tiles are cut at every 64th point counted from the start of the x-row (so dense rows give
+// full tiles: ~90 % lane fill) and a 64-chunk that spans more than `span` cell steps (sparse
+// rows) is cut again at aligned (span+1)-cell groups, which bounds the candidate count of a
+// tile: without the bound a sparse row yields tiles 20x the mean that the whole grid waits for.
 __global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict__ skeys,
                                                       DevCounters *__restrict__ ctr, uint32_t nx, uint32_t span,
+                                                      const uint2 *__restrict__ row_bounds,
                                                       uint2 *__restrict__ tiles, uint32_t tiles_cap)
 {
     __shared__ uint32_t wtot[1024 / kWave];
@@ -79,28 +89,24 @@ __global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict
     const uint32_t n = ctr->n_cropped;
     const uint32_t s = blockIdx.x * 1024u + threadIdx.x;
     if (blockIdx.x * 1024u >= n) return;  // uniform per block
-    uint32_t cnt = 0, e = 0;
+    const int w = threadIdx.x / kWave;
+    // a point starts a tile iff it starts a 64-chunk of its x-row, or its chunk is "sparse"
+    // (spans more than `span` cell steps) and it is the first point of an aligned cell group
+    uint32_t cnt = 0, cend = 0;
     if (s < n) {
         const uint32_t key = skeys[s];
         const uint32_t row = key / nx;
-        const uint32_t gx = (key - row * nx) / span;
-        bool start = true;
-        if (s != 0) {
-            const uint32_t pk = skeys[s - 1];
-            const uint32_t prow = pk / nx;
-            start = !(prow == row && (pk - prow * nx) / span == gx);
-        }
-        if (start) {
-            // one past the last point of this group
-            uint32_t kend = row * nx + (gx + 1u) * span;
-            if (kend > (row + 1u) * nx) kend = (row + 1u) * nx;
-            e = lower_bound_u32(skeys, n, kend);
-            cnt = (e - s + kWave - 1) / kWave;
+        const uint2 rb = row_bounds[row];  // written by k_gather_sorted
+        const uint32_t cstart = rb.x + ((s - rb.x) / (uint32_t)kTileQ) * (uint32_t)kTileQ;
+        cend = (cstart + kTileQ < rb.y) ? cstart + kTileQ : rb.y;
+        if (s == cstart) cnt = 1;
+        else if (skeys[cend - 1] - skeys[cstart] > span) {  // same row: key difference = cell steps
+            const uint32_t group = span + 1u;
+            if ((key - row * nx) / group != (skeys[s - 1] - row * nx) / group) cnt = 1;
         }
     }
-    // block-wide exclusive prefix of the tile counts, ONE atomic per block for the base
+    // block-wide exclusive prefix of the flags, ONE atomic per block for the base
     const uint32_t inc = wave_inclusive_scan(cnt);
-    const int w = threadIdx.x / kWave;
     if (lane_id() == kWave - 1) wtot[w] = inc;
     __syncthreads();
     uint32_t woff = 0, total = 0;
@@ -112,9 +118,8 @@ __global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict
     }
     if (threadIdx.x == 0) block_base = total ? atomicAdd(&ctr->n_tiles, total) : 0u;
     __syncthreads();
-    uint32_t t = block_base + woff + inc - cnt;
-    for (uint32_t b = s; cnt && b < e; b += kWave, ++t)
-        if (t < tiles_cap) tiles[t] = make_uint2(b, (e - b < (uint32_t)kWave) ? e - b : (uint32_t)kWave);
+    const uint32_t t_out = block_base + woff + inc - cnt;
+    if (cnt && t_out < tiles_cap) tiles[t_out] = make_uint2(s, cend);  // start, end of its 64-chunk
 }
 
 // ---- smallest eigenpair of a symmetric PSD 3x3, fp64 ----------------------------
@@ -180,7 +185,8 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
                                                         const uint32_t *__restrict__ skeys,
                                                         const uint2 *__restrict__ tiles,
                                                         DevCounters *__restrict__ ctr, GridParams g,
-                                                        uint32_t tiles_cap, float4 *__restrict__ normals4,
+                                                        uint32_t tiles_cap, const uint2 *__restrict__ row_bounds,
+                                                        float4 *__restrict__ normals4,
                                                         int32_t *__restrict__ counts, VoxDense vd,
                                                         VoxCell *__restrict__ vox_table)
 {
@@ -199,10 +205,27 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
         t = __shfl(t, 0, kWave);
         if (t >= ntiles) break;  // every wave reaches this: the queue only grows
         const uint2 tile = tiles[t];
-        const uint32_t qs = tile.x, qn = tile.y;
+        const uint32_t qs = tile.x, cend = tile.y;
+        // the tile = points from qs up to the end of its 64-chunk or, in a sparse chunk, of its cell group
+        const uint32_t ka = skeys[qs];
+        uint32_t qn;
+        {
+            const uint32_t rowa = ka / (uint32_t)g.nx;
+            const uint32_t rstart = row_bounds[rowa].x;
+            const uint32_t cstart = rstart + ((qs - rstart) / (uint32_t)kTileQ) * (uint32_t)kTileQ;
+            const bool sparse = skeys[cend - 1] - skeys[cstart] > (uint32_t)kTileSpan;
+            const uint32_t group = (uint32_t)kTileSpan + 1u;
+            bool mine = qs + lane < cend;
+            if (mine && sparse) {
+                const uint32_t kl = skeys[qs + lane];
+                mine = (kl - rowa * (uint32_t)g.nx) / group == (ka - rowa * (uint32_t)g.nx) / group;
+            }
+            const uint64_t mask = __ballot(mine);
+            qn = (~mask == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~mask);  // same-group lanes are contiguous from lane 0
+        }
 
         // tile geometry: one x-row, cells [cxa, cxb]
-        const uint32_t ka = skeys[qs], kb = skeys[qs + qn - 1];
+        const uint32_t kb = skeys[qs + qn - 1];
         const uint32_t row = ka / (uint32_t)g.nx;
         const int cxa = (int)(ka - row * (uint32_t)g.nx), cxb = (int)(kb - row * (uint32_t)g.nx);
         const int cy = (int)(row % (uint32_t)g.ny), cz = (int)(row / (uint32_t)g.ny);
@@ -232,40 +255,49 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
         }
         const uint32_t total = rpre[9];
 
-        // this lane's query
-        const bool active = (uint32_t)lane < qn;
-        const float4 q = spts4[qs + (active ? lane : 0)];
+        // this lane's query: kSplit lanes share a query, lane part p takes candidate groups p, p+kSplit, ...
+        const int ql = lane & (kTileQ - 1), part = lane / kTileQ;
+        const bool active = (uint32_t)ql < qn && part == 0;
+        const float4 q = spts4[qs + ((uint32_t)ql < qn ? ql : 0)];
 
         double Sn = 0, Sx = 0, Sy = 0, Sz = 0, Sxx = 0, Sxy = 0, Sxz = 0, Syy = 0, Syz = 0, Szz = 0;
         const v2f qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
         const v2f r2v = {g.r2, g.r2};
         const float *wx = &win[w][0][0], *wy = &win[w][1][0], *wz = &win[w][2][0];
 
-        for (uint32_t v0 = 0; v0 < total; v0 += kWave) {
-            // map the flattened candidate index to its range
+        // candidate fetch for window v0: flattened candidate index -> its range -> sorted array
+        auto fetch = [&](uint32_t v0) -> float4 {
             const uint32_t vv = v0 + lane;
-            float4 cp = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);  // never within r of anything
+            float4 cpv = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);  // never within r of anything
             if (vv < total) {
                 uint32_t src = rbeg[0] + vv;
 #pragma unroll
                 for (int r = 1; r < 9; ++r)
                     if (vv >= rpre[r]) src = rbeg[r] + (vv - rpre[r]);
-                cp = spts4[src];
+                cpv = spts4[src];
             }
+            return cpv;
+        };
+        float4 cp_next = fetch(0);
+        for (uint32_t v0 = 0; v0 < total; v0 += kWave) {
+            const float4 cp = cp_next;
             wave_lds_fence();  // previous window fully consumed
             win[w][0][lane] = cp.x; win[w][1][lane] = cp.y; win[w][2][lane] = cp.z;
             wave_lds_fence();
+            cp_next = fetch(v0 + kWave);  // in flight while this window is consumed
             const int m = (total - v0 < (uint32_t)kWave) ? (int)(total - v0) : kWave;
-            const int groups = (m + 3) >> 2;  // padding slots hold far-away points
+            const int groups = ((m + 3) >> 2) + (kSplit - 1);  // padding slots hold far-away points
+            const int iters = groups / kSplit;
             // branch-free, two candidates per packed instruction (v_pk_*_f32): the
             // inlier test becomes a 0/1 weight so nothing in the loop touches EXEC
             v2f sn = {0, 0}, sx = {0, 0}, sy = {0, 0}, sz = {0, 0}, sxx = {0, 0}, sxy = {0, 0}, sxz = {0, 0},
                 syy = {0, 0}, syz = {0, 0}, szz = {0, 0};
-            float4 nx4 = *reinterpret_cast<const float4 *>(wx), ny4 = *reinterpret_cast<const float4 *>(wy),
-                   nz4 = *reinterpret_cast<const float4 *>(wz);
-            for (int gidx = 0; gidx < groups; ++gidx) {
+            // lanes of one part read the same address (LDS broadcast); parts read neighbouring groups
+            float4 nx4 = *reinterpret_cast<const float4 *>(wx + 4 * part), ny4 = *reinterpret_cast<const float4 *>(wy + 4 * part),
+                   nz4 = *reinterpret_cast<const float4 *>(wz + 4 * part);
+            for (int gidx = 0; gidx < iters; ++gidx) {
                 const float4 cx4 = nx4, cy4 = ny4, cz4 = nz4;
-                const int nj = (gidx + 1 < groups) ? (gidx + 1) * 4 : 0;  // prefetch the next group (same address in every lane)
+                const int nj = (gidx + 1 < iters) ? ((gidx + 1) * kSplit + part) * 4 : 0;  // prefetch the next group
                 nx4 = *reinterpret_cast<const float4 *>(wx + nj);
                 ny4 = *reinterpret_cast<const float4 *>(wy + nj);
                 nz4 = *reinterpret_cast<const float4 *>(wz + nj);
@@ -293,6 +325,12 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
             Sxx += (double)sxx.x + (double)sxx.y; Sxy += (double)sxy.x + (double)sxy.y;
             Sxz += (double)sxz.x + (double)sxz.y; Syy += (double)syy.x + (double)syy.y;
             Syz += (double)syz.x + (double)syz.y; Szz += (double)szz.x + (double)szz.y;
+        }
+        if (kSplit == 2) {  // join the two halves of every query's sums
+            Sn += __shfl_xor(Sn, 32, kWave);
+            Sx += __shfl_xor(Sx, 32, kWave); Sy += __shfl_xor(Sy, 32, kWave); Sz += __shfl_xor(Sz, 32, kWave);
+            Sxx += __shfl_xor(Sxx, 32, kWave); Sxy += __shfl_xor(Sxy, 32, kWave); Sxz += __shfl_xor(Sxz, 32, kWave);
+            Syy += __shfl_xor(Syy, 32, kWave); Syz += __shfl_xor(Syz, 32, kWave); Szz += __shfl_xor(Szz, 32, kWave);
         }
         const int cnt = (int)Sn;
 
@@ -360,10 +398,10 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
 
 uint32_t max_tiles(uint32_t n_cap, const GridParams &g)
 {
-    // every cell group adds at most one partially filled tile
-    const uint64_t groups = (uint64_t)g.ny * (uint64_t)g.nz * (uint64_t)((g.nx + kTileSpan - 1) / kTileSpan);
-    const uint64_t extra = groups < n_cap ? groups : n_cap;
-    return (uint32_t)(n_cap / kWave + extra + 1);
+    // every aligned cell group adds at most one partially filled tile, every 64-chunk at most one more
+    const uint64_t groups = (uint64_t)g.ny * (uint64_t)g.nz * (uint64_t)((g.nx + kTileSpan) / (kTileSpan + 1));
+    const uint64_t extra = (groups < n_cap ? groups : n_cap) + n_cap / kTileQ;
+    return (uint32_t)(n_cap / kTileQ + extra + 1);
 }
 
 void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, uint32_t n_cap, bool keep_counts,
@@ -381,16 +419,17 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     sl.skeys = skeys;
     const uint32_t gb = (n_cap + 255) / 256 < 2048 ? (n_cap + 255) / 256 : 2048;
     hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(256), 0, s, (const float4 *)sl.crop4, (const uint32_t *)perm,
-                       (const uint32_t *)&sl.ctr->n_cropped, sl.spts4);
+                       (const uint32_t *)skeys, (const uint32_t *)&sl.ctr->n_cropped, (uint32_t)g.nx, sl.spts4,
+                       sl.row_bounds);
     hipLaunchKernelGGL(k_build_tiles, dim3((n_cap + 1023) / 1024), dim3(1024), 0, s, (const uint32_t *)skeys, sl.ctr, (uint32_t)g.nx,
-                       (uint32_t)kTileSpan, sl.tiles, sl.tiles_cap);
+                       (uint32_t)kTileSpan, (const uint2 *)sl.row_bounds, sl.tiles, sl.tiles_cap);
     // persistent grid: 8 blocks of 4 waves per CU fill every SIMD's 8 wave slots
     const uint32_t mt = max_tiles(n_cap, g);
     uint32_t nb = (mt + kNrWaves - 1) / kNrWaves;
     if (nb > 2048) nb = 2048;
     hipEventRecord(sl.ev_k0, s);
     hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), 0, s, (const float4 *)sl.spts4, (const uint32_t *)skeys,
-                       (const uint2 *)sl.tiles, sl.ctr, g, sl.tiles_cap, sl.normals4,
+                       (const uint2 *)sl.tiles, sl.ctr, g, sl.tiles_cap, (const uint2 *)sl.row_bounds, sl.normals4,
                        keep_counts ? sl.counts : (int32_t *)nullptr, vd, sl.vox_table);
     hipEventRecord(sl.ev_k1, s);
 }
