@@ -21,7 +21,7 @@
 namespace gm {
 
 constexpr int kScThreads = 256;
-constexpr int kScP = 4;                       // points staged per thread
+constexpr int kScP = 1;                       // points staged per thread (small blocks: short tail)
 constexpr int kScTile = kScThreads * kScP;    // points per block
 constexpr int kMaxDraws = 64;
 
@@ -202,11 +202,11 @@ __global__ __launch_bounds__(kScThreads) void k_score(const float4 *__restrict__
         g[(j & 3)] = v.x; g[4 + (j & 3)] = v.y; g[8 + (j & 3)] = v.z;
     }
     float hp[kScHPL][8];
-    uint32_t c[kScHPL];
+    float c[kScHPL];  // float counters (exact: <= kScTile per block): keeps the compiler on cmp+cndmask+add
 #pragma unroll
     for (int k = 0; k < kScHPL; ++k) {
         const uint32_t h = blockIdx.y * kScHC + k * kScThreads + threadIdx.x;
-        c[k] = 0;
+        c[k] = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) hp[k][q] = 0.f;
         hp[k][0] = __builtin_nanf("");  // lanes past H score nothing
@@ -229,17 +229,17 @@ __global__ __launch_bounds__(kScThreads) void k_score(const float4 *__restrict__
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (MODEL == 0)
-                    c[k] += plane_inlier(xs[q], ys[q], zs[q], hp[k][0], hp[k][1], hp[k][2], hp[k][3], tau) ? 1u : 0u;
+                    c[k] += plane_inlier(xs[q], ys[q], zs[q], hp[k][0], hp[k][1], hp[k][2], hp[k][3], tau) ? 1.0f : 0.0f;
                 else
                     c[k] += cyl_inlier(xs[q], ys[q], zs[q], hp[k][0], hp[k][1], hp[k][2], hp[k][3], hp[k][4], hp[k][5],
-                                       hp[k][6], hp[k][7]) ? 1u : 0u;
+                                       hp[k][6], hp[k][7]) ? 1.0f : 0.0f;
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < kScHPL; ++k) {
         const uint32_t h = blockIdx.y * kScHC + k * kScThreads + threadIdx.x;
-        if (h < H && c[k]) atomicAdd(&counts[h], (int32_t)c[k]);
+        if (h < H && c[k] > 0.f) atomicAdd(&counts[h], (int32_t)c[k]);
     }
 }
 
