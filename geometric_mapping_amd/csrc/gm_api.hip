@@ -52,7 +52,8 @@ void free_slot_buffers(Slot &sl)
     sl.cap = 0; sl.raw_cap = 0; sl.tiles_cap = 0;
 }
 
-// search grid over the crop box [-b, b]^3 (cell edge >= 1.001 r, <= 1024 cells per axis)
+// search grid over the crop box: cell edge >= 1.001 r in y and z (<= 1024 cells per axis), x binned
+// `fine` times finer (a power of two chosen so that the cell key still fits 31 bits)
 GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, float ez, double radius)
 {
     GridParams g;
@@ -62,8 +63,14 @@ GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, flo
     if (h < ext / 1023.0f) h = ext / 1023.0f;
     g.ox = lo_x; g.oy = lo_y; g.oz = lo_z;
     g.inv_h = 1.0f / h;
-    auto dim = [&](float e) { int n = (int)floorf(e * g.inv_h) + 1; return n < 1 ? 1 : (n > 1024 ? 1024 : n); };
-    g.nx = dim(ex); g.ny = dim(ey); g.nz = dim(ez);
+    auto dim = [&](float e, float inv, int cap) { int n = (int)floorf(e * inv) + 1; return n < 1 ? 1 : (n > cap ? cap : n); };
+    g.ny = dim(ey, g.inv_h, 1024); g.nz = dim(ez, g.inv_h, 1024);
+    const int nxc = dim(ex, g.inv_h, 1024);
+    int fine = 16;
+    while (fine > 1 && (uint64_t)g.ny * g.nz * (uint64_t)(nxc * fine + fine) >= (1ull << 31)) fine >>= 1;
+    g.inv_hx = g.inv_h * (float)fine;
+    g.nx = dim(ex, g.inv_hx, 1024 * fine);
+    g.xreach = fine + 1;
     g.r2 = (float)(radius * radius);  // KdTreeFLANN::radiusSearch: static_cast<float>(radius*radius)
     return g;
 }

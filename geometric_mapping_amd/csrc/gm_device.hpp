@@ -38,8 +38,12 @@ struct VoxelParams {
 // kd-tree of src/tunnel_processing.cpp:62-63: same neighbour sets).
 struct GridParams {
     float ox, oy, oz;   // origin (lower corner)
-    float inv_h;        // 1 / cell edge, edge >= 1.001 * radius
-    int32_t nx, ny, nz;
+    float inv_h;        // 1 / cell edge in y and z, edge >= 1.001 * radius
+    float inv_hx;       // 1 / cell edge in x = fine * inv_h: x is binned `fine` times finer, so that
+                        // the points of one x-row are sorted by x and candidate ranges can be cut to
+                        // [xmin - r, xmax + r] of a tile instead of whole cells
+    int32_t nx, ny, nz; // cells per axis (nx counts the fine x cells)
+    int32_t xreach;     // fine x cells that cover the radius (fine + 1)
     float r2;           // (float)(radius*radius): KdTreeFLANN::radiusSearch's cast
 };
 
@@ -173,7 +177,7 @@ __device__ __forceinline__ int cell_coord(float x, float o, float inv_h, int n)
 
 __device__ __forceinline__ uint32_t cell_key(const GridParams &g, float x, float y, float z)
 {
-    int cx = cell_coord(x, g.ox, g.inv_h, g.nx);
+    int cx = cell_coord(x, g.ox, g.inv_hx, g.nx);
     int cy = cell_coord(y, g.oy, g.inv_h, g.ny);
     int cz = cell_coord(z, g.oz, g.inv_h, g.nz);
     return (uint32_t)((cz * g.ny + cy) * g.nx + cx);

@@ -50,7 +50,7 @@ __device__ __forceinline__ v2f pk_add_rn(v2f a, v2f b)
 constexpr int kNrThreads = 256;
 constexpr int kSplit = 1;                 // lanes per query: each handles 1/kSplit of the tile's candidates
 constexpr int kTileQ = kWave / kSplit;    // queries per tile
-constexpr int kTileSpan = 3;              // max cell steps (last cell - first cell) inside one tile
+constexpr int kTileSpan = 3;              // max x extent of one tile, in (coarse) cell edges
 constexpr int kNrWaves = kNrThreads / kWave;
 
 // ---- gather the cropped cloud into cell-sorted order ---------------------------
@@ -213,8 +213,9 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
             const uint32_t rowa = ka / (uint32_t)g.nx;
             const uint32_t rstart = row_bounds[rowa].x;
             const uint32_t cstart = rstart + ((qs - rstart) / (uint32_t)kTileQ) * (uint32_t)kTileQ;
-            const bool sparse = skeys[cend - 1] - skeys[cstart] > (uint32_t)kTileSpan;
-            const uint32_t group = (uint32_t)kTileSpan + 1u;
+            const uint32_t span = (uint32_t)(kTileSpan * (g.xreach - 1));
+            const bool sparse = skeys[cend - 1] - skeys[cstart] > span;
+            const uint32_t group = span + 1u;
             bool mine = qs + lane < cend;
             if (mine && sparse) {
                 const uint32_t kl = skeys[qs + lane];
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
         const uint32_t row = ka / (uint32_t)g.nx;
         const int cxa = (int)(ka - row * (uint32_t)g.nx), cxb = (int)(kb - row * (uint32_t)g.nx);
         const int cy = (int)(row % (uint32_t)g.ny), cz = (int)(row / (uint32_t)g.ny);
-        const int x0 = cxa > 0 ? cxa - 1 : 0, x1 = cxb < g.nx - 1 ? cxb + 1 : g.nx - 1;
+        // x-rows are sorted by fine x cell: candidates are exactly the points within `xreach` fine cells (>= r)
+        const int x0 = cxa > g.xreach ? cxa - g.xreach : 0, x1 = cxb + g.xreach < g.nx - 1 ? cxb + g.xreach : g.nx - 1;
 
         // 9 candidate ranges (one per neighbouring x-row); lanes 0..8 find begin,
         // lanes 16..24 find end, by binary search in the sorted keys
@@ -399,7 +401,8 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
 uint32_t max_tiles(uint32_t n_cap, const GridParams &g)
 {
     // every aligned cell group adds at most one partially filled tile, every 64-chunk at most one more
-    const uint64_t groups = (uint64_t)g.ny * (uint64_t)g.nz * (uint64_t)((g.nx + kTileSpan) / (kTileSpan + 1));
+    const uint64_t span = (uint64_t)kTileSpan * (uint64_t)(g.xreach - 1);
+    const uint64_t groups = (uint64_t)g.ny * (uint64_t)g.nz * ((uint64_t)g.nx / (span + 1) + 1);
     const uint64_t extra = (groups < n_cap ? groups : n_cap) + n_cap / kTileQ;
     return (uint32_t)(n_cap / kTileQ + extra + 1);
 }
@@ -422,7 +425,7 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
                        (const uint32_t *)skeys, (const uint32_t *)&sl.ctr->n_cropped, (uint32_t)g.nx, sl.spts4,
                        sl.row_bounds);
     hipLaunchKernelGGL(k_build_tiles, dim3((n_cap + 1023) / 1024), dim3(1024), 0, s, (const uint32_t *)skeys, sl.ctr, (uint32_t)g.nx,
-                       (uint32_t)kTileSpan, (const uint2 *)sl.row_bounds, sl.tiles, sl.tiles_cap);
+                       (uint32_t)(kTileSpan * (g.xreach - 1)), (const uint2 *)sl.row_bounds, sl.tiles, sl.tiles_cap);
     // persistent grid: 8 blocks of 4 waves per CU fill every SIMD's 8 wave slots
     const uint32_t mt = max_tiles(n_cap, g);
     uint32_t nb = (mt + kNrWaves - 1) / kNrWaves;
