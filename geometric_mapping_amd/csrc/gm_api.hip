@@ -371,7 +371,7 @@ gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H)
     const uint32_t HH = H > sl.ext_H ? H : sl.ext_H;
     GM_HIP(ctx, dmalloc(sl.hyp_plane, (size_t)HH * 8)); GM_HIP(ctx, dmalloc(sl.hyp_cyl, (size_t)HH * 8));
     GM_HIP(ctx, dmalloc(sl.band, HH));
-    GM_HIP(ctx, dmalloc(sl.score_partial, (size_t)(score_blocks(sl.cap) + 1) * HH));
+    GM_HIP(ctx, dmalloc(sl.score_partial, (size_t)256));  // pre-selection scratch: sel[64] + counts_k[64]
     GM_HIP(ctx, dmalloc(sl.cnt_plane, HH)); GM_HIP(ctx, dmalloc(sl.cnt_cyl, HH));
     GM_HIP(ctx, dmalloc(sl.best_plane, 2)); GM_HIP(ctx, dmalloc(sl.best_cyl, 2));
     GM_HIP(ctx, dmalloc(sl.mom_partial, (size_t)kScatterBlocks * 16));
@@ -398,16 +398,16 @@ gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap)
     GM_HIP(ctx, hipMemsetAsync(sl.best_cyl, 0xFF, 8, s));
     if (do_plane) {
         launch_plane_hypotheses(sl.valid4, sl.labels, 0, n_ptr, n_cap, cf.ransac_seed, H, sl.hyp_plane, s);
-        launch_score(0, sl.valid4, sl.labels, 0, n_ptr, n_cap, sl.hyp_plane, sl.band, H, cf.ransac_threshold,
-                     sl.score_partial, sl.cnt_plane, sl.best_plane, s);
+        launch_score_preemptive(0, sl.valid4, sl.labels, 0, n_ptr, n_cap, sl.hyp_plane, sl.band, H, cf.ransac_threshold,
+                                sl.score_partial, sl.cnt_plane, sl.best_plane, s);
         launch_label(0, sl.valid4, sl.labels, 0, 1, n_ptr, n_cap, sl.hyp_plane, sl.band, sl.best_plane,
                      cf.ransac_threshold, s);
         launch_segment_moments(sl.valid4, sl.vnorm4, sl.labels, 1, n_ptr, n_cap, sl.mom_partial, sl.mom_plane, s);
     }
     if (do_cyl) {
         launch_cylinder_hypotheses(sl.valid4, sl.vnorm4, sl.labels, 0, n_ptr, n_cap, cf.ransac_seed + 1, H, sl.hyp_cyl, s);
-        launch_score(1, sl.valid4, sl.labels, 0, n_ptr, n_cap, sl.hyp_cyl, sl.band, H, cf.ransac_threshold,
-                     sl.score_partial, sl.cnt_cyl, sl.best_cyl, s);
+        launch_score_preemptive(1, sl.valid4, sl.labels, 0, n_ptr, n_cap, sl.hyp_cyl, sl.band, H, cf.ransac_threshold,
+                                sl.score_partial, sl.cnt_cyl, sl.best_cyl, s);
         launch_label(1, sl.valid4, sl.labels, 0, 2, n_ptr, n_cap, sl.hyp_cyl, sl.band, sl.best_cyl,
                      cf.ransac_threshold, s);
         launch_segment_moments(sl.valid4, sl.vnorm4, sl.labels, 2, n_ptr, n_cap, sl.mom_partial, sl.mom_cyl, s);

@@ -16,6 +16,7 @@
 //   s_bcnt1 counts it; per-block sums go through LDS, per-block rows to HBM with plain
 //   stores, and a second kernel sums the rows in fixed order and picks the arg-max.
 //   No float atomics anywhere: counts are integers, results are run-to-run identical.
+// (The paragraph above describes k_score_few; k_score, the H-wide scorer, maps lane <-> hypothesis.)
 #include "gm_internal.hpp"
 
 namespace gm {
@@ -180,12 +181,14 @@ __global__ __launch_bounds__(kScThreads) void k_score(const float4 *__restrict__
                                                       const uint32_t *__restrict__ n_ptr, uint32_t n_host,
                                                       const float *__restrict__ hyp8,
                                                       const float2 *__restrict__ band, uint32_t H, float tau,
-                                                      int32_t *__restrict__ counts)
+                                                      uint32_t stride, int32_t *__restrict__ counts)
 {
     // points in LDS as groups of four, SoA inside a group: x0..x3 | y0..y3 | z0..z3, so three
     // broadcast ds_read_b128 deliver four points
     __shared__ float4 lp[kScTile / 4][3];
-    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    // with stride > 1 only every stride-th point is scored (the pre-selection stage of the in-frame RANSAC)
+    const uint32_t n_full = n_ptr ? *n_ptr : n_host;
+    const uint32_t n = (n_full + stride - 1) / stride;
     const uint32_t base = blockIdx.x * kScTile;
     if (base >= n) return;  // uniform per block
     const uint32_t m = (n - base < (uint32_t)kScTile) ? n - base : (uint32_t)kScTile;
@@ -193,8 +196,8 @@ __global__ __launch_bounds__(kScThreads) void k_score(const float4 *__restrict__
 #pragma unroll
     for (int p = 0; p < kScP; ++p) {
         const uint32_t j = p * kScThreads + threadIdx.x;
-        const uint32_t i = base + j;
-        bool ok = i < n;
+        const uint32_t i = (base + j) * stride;
+        bool ok = base + j < n;
         if (ok && labels) ok = labels[i] == want;
         float4 v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 0.f);
         if (ok) v = pts[i];  // masked / out-of-range points are NaN: never an inlier
@@ -266,6 +269,93 @@ __global__ __launch_bounds__(1024) void k_best_hypothesis(const int32_t *__restr
         __syncthreads();
     }
     if (threadIdx.x == 0) { best[0] = bi[0]; best[1] = bc[0]; }
+}
+
+// ---- pre-selection: keep the K best hypotheses of the sub-sampled scores (count desc, index asc) ----
+constexpr int kPreStride = 8;   // stage 1 scores every 8th point
+constexpr int kPreKeep = 64;    // stage 2 re-scores this many hypotheses on every point
+
+__global__ __launch_bounds__(1024) void k_select_topk(const int32_t *__restrict__ counts, uint32_t H, uint32_t K,
+                                                      uint32_t *__restrict__ sel)
+{
+    extern __shared__ int32_t lc[];  // [H]
+    for (uint32_t h = threadIdx.x; h < H; h += 1024) lc[h] = counts[h];
+    __syncthreads();
+    for (uint32_t h = threadIdx.x; h < H; h += 1024) {
+        const int32_t c = lc[h];
+        uint32_t rank = 0;
+        for (uint32_t o = 0; o < H; ++o) {
+            const int32_t co = lc[o];
+            rank += (co > c || (co == c && o < h)) ? 1u : 0u;
+        }
+        if (rank < K) sel[rank] = h;  // ranks are a permutation: every slot < min(K,H) is written exactly once
+    }
+}
+
+// lane <-> point, few hypotheses (K <= 64) staged in LDS: the inlier test's v_cmp result IS the wave
+// ballot, s_bcnt1 counts it, one LDS atomic per (wave, hypothesis), one global atomic per (block, hypothesis)
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_score_few(const float4 *__restrict__ pts, const uint8_t *__restrict__ labels,
+                                                   uint32_t want, const uint32_t *__restrict__ n_ptr, uint32_t n_host,
+                                                   const float *__restrict__ hyp8, const float2 *__restrict__ band,
+                                                   const uint32_t *__restrict__ sel, uint32_t K, float tau,
+                                                   int32_t *__restrict__ counts_k)
+{
+    constexpr int P = 4;
+    __shared__ __attribute__((aligned(16))) float lh[kPreKeep][8];
+    __shared__ float2 lb[kPreKeep];
+    __shared__ uint32_t lcnt[kPreKeep];
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    const uint32_t base = blockIdx.x * 256u * P;
+    if (base >= n) return;  // uniform per block
+    for (uint32_t k = threadIdx.x; k < K * 8; k += 256) lh[k >> 3][k & 7] = hyp8[8 * (size_t)sel[k >> 3] + (k & 7)];
+    if (threadIdx.x < K) {
+        lcnt[threadIdx.x] = 0;
+        lb[threadIdx.x] = MODEL == 1 ? band[sel[threadIdx.x]] : make_float2(0.f, 0.f);
+    }
+    float px[P], py[P], pz[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const uint32_t i = base + p * 256u + threadIdx.x;
+        bool ok = i < n;
+        if (ok && labels) ok = labels[i] == want;
+        float4 v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 0.f);
+        if (ok) v = pts[i];
+        px[p] = v.x; py[p] = v.y; pz[p] = v.z;
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < K; ++k) {
+        const float4 ha = *reinterpret_cast<const float4 *>(&lh[k][0]);
+        const float4 hb = *reinterpret_cast<const float4 *>(&lh[k][4]);
+        const float2 bd = lb[k];
+        uint32_t c = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const bool in = MODEL == 0 ? plane_inlier(px[p], py[p], pz[p], ha.x, ha.y, ha.z, ha.w, tau)
+                                       : cyl_inlier(px[p], py[p], pz[p], ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, bd.x, bd.y);
+            c += (uint32_t)__popcll(__ballot(in));
+        }
+        if (lane_id() == 0 && c) atomicAdd(&lcnt[k], c);
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        const uint32_t c = lcnt[threadIdx.x];
+        if (c) atomicAdd(&counts_k[threadIdx.x], (int32_t)c);
+    }
+}
+
+// winner among the re-scored hypotheses: largest full count, lowest hypothesis index on ties
+__global__ __launch_bounds__(64) void k_best_of_selected(const int32_t *__restrict__ counts_k,
+                                                         const uint32_t *__restrict__ sel, uint32_t K,
+                                                         uint32_t *__restrict__ best)
+{
+    if (threadIdx.x != 0) return;
+    uint32_t bi = 0xFFFFFFFFu, bc = 0;
+    for (uint32_t k = 0; k < K; ++k) {
+        const uint32_t c = (uint32_t)counts_k[k], h = sel[k];
+        if (bi == 0xFFFFFFFFu || c > bc || (c == bc && h < bi)) { bc = c; bi = h; }
+    }
+    best[0] = bi; best[1] = bc;
 }
 
 template <int MODEL>
@@ -418,13 +508,50 @@ void launch_score(int model, const float4 *pts, const uint8_t *labels, uint32_t 
     hipMemsetAsync(counts, 0, sizeof(int32_t) * H, s);
     if (model == 0) {
         hipLaunchKernelGGL(k_score<0>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
-                           (const float2 *)band, H, (float)tau, counts);
+                           (const float2 *)band, H, (float)tau, 1u, counts);
     } else {
         hipLaunchKernelGGL(k_cyl_bands, dim3((H + 255) / 256), dim3(256), 0, s, hyp8, H, tau, band);
         hipLaunchKernelGGL(k_score<1>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
-                           (const float2 *)band, H, (float)tau, counts);
+                           (const float2 *)band, H, (float)tau, 1u, counts);
     }
     hipLaunchKernelGGL(k_best_hypothesis, dim3(1), dim3(1024), 0, s, (const int32_t *)counts, H, best);
+}
+
+// In-frame RANSAC: preemptive scoring.  Stage 1 scores all H hypotheses on every kPreStride-th point,
+// stage 2 re-scores the kPreKeep best of them on every point; the winner is the best full count.
+// `scratch` holds sel[kPreKeep] followed by counts_k[kPreKeep].
+void launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels, uint32_t want,
+                             const uint32_t *n_ptr, uint32_t n_cap, const float *hyp8, float2 *band, uint32_t H,
+                             double tau, uint32_t *scratch, int32_t *counts, uint32_t *best, hipStream_t s)
+{
+    if (H <= (uint32_t)kPreKeep) {  // nothing to pre-select
+        launch_score(model, pts, labels, want, n_ptr, n_cap, hyp8, band, H, tau, nullptr, counts, best, s);
+        return;
+    }
+    const uint32_t n_sub = (n_cap + kPreStride - 1) / kPreStride;
+    const uint32_t nb = score_blocks(n_sub) ? score_blocks(n_sub) : 1;
+    const dim3 grid(nb, (H + kScHC - 1) / kScHC);
+    uint32_t *sel = scratch;
+    int32_t *counts_k = (int32_t *)(scratch + kPreKeep);
+    hipMemsetAsync(counts, 0, sizeof(int32_t) * H, s);
+    hipMemsetAsync(counts_k, 0, sizeof(int32_t) * kPreKeep, s);
+    if (model == 1) hipLaunchKernelGGL(k_cyl_bands, dim3((H + 255) / 256), dim3(256), 0, s, hyp8, H, tau, band);
+    const uint32_t K = kPreKeep;
+    const uint32_t nbf = (n_cap + 1023) / 1024 ? (n_cap + 1023) / 1024 : 1;
+    if (model == 0) {
+        hipLaunchKernelGGL(k_score<0>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
+                           (const float2 *)band, H, (float)tau, (uint32_t)kPreStride, counts);
+        hipLaunchKernelGGL(k_select_topk, dim3(1), dim3(1024), sizeof(int32_t) * H, s, (const int32_t *)counts, H, K, sel);
+        hipLaunchKernelGGL(k_score_few<0>, dim3(nbf), dim3(256), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
+                           (const float2 *)band, (const uint32_t *)sel, K, (float)tau, counts_k);
+    } else {
+        hipLaunchKernelGGL(k_score<1>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
+                           (const float2 *)band, H, (float)tau, (uint32_t)kPreStride, counts);
+        hipLaunchKernelGGL(k_select_topk, dim3(1), dim3(1024), sizeof(int32_t) * H, s, (const int32_t *)counts, H, K, sel);
+        hipLaunchKernelGGL(k_score_few<1>, dim3(nbf), dim3(256), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
+                           (const float2 *)band, (const uint32_t *)sel, K, (float)tau, counts_k);
+    }
+    hipLaunchKernelGGL(k_best_of_selected, dim3(1), dim3(64), 0, s, (const int32_t *)counts_k, (const uint32_t *)sel, K, best);
 }
 
 void launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, uint32_t label, const uint32_t *n_ptr,

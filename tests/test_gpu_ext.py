@@ -100,6 +100,21 @@ def test_nearest(ctx, oc):
     assert ctx.nearest(xyz[:1], cen).tolist() == [0] * len(cen)
 
 
+def preemptive_best(score_fn, cloud, hyp, labels, want=0, stride=8, keep=64):
+    """The in-frame RANSAC's two-stage scoring (csrc/k_ransac.hip launch_score_preemptive), restated with the
+    oracle's exhaustive scorer: all hypotheses on every 8th point -> 64 best (count desc, index asc) -> those on
+    every point -> best full count (lowest index on ties)."""
+    if len(hyp) <= keep:
+        c = score_fn(cloud, hyp, TAU, labels, want)
+        k = np.lexsort((np.arange(len(hyp)), -c))[0]
+        return int(k), int(c[k])
+    c1 = score_fn(cloud[::stride], hyp, TAU, labels[::stride], want)
+    sel = np.lexsort((np.arange(len(hyp)), -c1))[:keep]
+    c2 = score_fn(cloud, hyp[sel], TAU, labels, want)
+    k = np.lexsort((sel, -c2))[0]
+    return int(sel[k]), int(c2[k])
+
+
 def test_frame_ransac_plane_then_cylinder(gm, oc):
     from geometric_mapping_amd import _lib
     xyz = synth.tunnel_frame(60000, seed=2, floor_z=-1.2, outlier_frac=0.01)
@@ -116,15 +131,14 @@ def test_frame_ransac_plane_then_cylinder(gm, oc):
     # the same sequence on the CPU restatement, fed the GPU's own cloud+normals
     labels = np.zeros(len(cloud), np.uint8)
     hp = oc.plane_hypotheses(cloud, seed, H, labels, 0)
-    cp = oc.score_planes(cloud, hp, TAU, labels, 0)
-    bp = int(np.argmax(cp))
-    assert res["plane_inliers"] == cp[bp]
+    bp, nbp = preemptive_best(oc.score_planes, cloud, hp, labels)
+    assert res["plane_inliers"] == nbp
     assert np.abs(res["plane"] - hp[bp]).max() < 1e-5
+    assert nbp >= 0.98 * oc.score_planes(cloud, hp, TAU, labels, 0).max()   # pre-selection loses (almost) nothing
     assert oc.label_plane(cloud, labels, 0, 1, res["plane"], TAU) == res["plane_inliers"]
     hc = oc.cylinder_hypotheses(cloud, nrm, seed + 1, H, labels, 0)
-    cc = oc.score_cylinders(cloud, hc, TAU, labels, 0)
-    bc = int(np.argmax(cc))
-    assert abs(int(res["cylinder_inliers"]) - int(cc[bc])) <= 2     # hypotheses agree to 1e-6, not bit for bit
+    bc, nbc = preemptive_best(oc.score_cylinders, cloud, hc, labels)
+    assert abs(int(res["cylinder_inliers"]) - nbc) <= 2             # hypotheses agree to 1e-6, not bit for bit
     assert oc.label_cylinder(cloud, labels, 0, 2, res["cylinder"], TAU) == res["cylinder_inliers"]
     assert np.array_equal(lab, labels)
     # refits vs the restatement on the same labels
