@@ -275,21 +275,22 @@ __global__ __launch_bounds__(1024) void k_best_hypothesis(const int32_t *__restr
 constexpr int kPreStride = 8;   // stage 1 scores every 8th point
 constexpr int kPreKeep = 64;    // stage 2 re-scores this many hypotheses on every point
 
-__global__ __launch_bounds__(1024) void k_select_topk(const int32_t *__restrict__ counts, uint32_t H, uint32_t K,
-                                                      uint32_t *__restrict__ sel)
+__global__ __launch_bounds__(64) void k_select_topk(const int32_t *__restrict__ counts, uint32_t H, uint32_t K,
+                                                    uint32_t *__restrict__ sel)
 {
+    // one wave per 64 hypotheses, each lane ranks its hypothesis against all H counts (staged in LDS)
     extern __shared__ int32_t lc[];  // [H]
-    for (uint32_t h = threadIdx.x; h < H; h += 1024) lc[h] = counts[h];
+    for (uint32_t h = threadIdx.x; h < H; h += 64) lc[h] = counts[h];
     __syncthreads();
-    for (uint32_t h = threadIdx.x; h < H; h += 1024) {
-        const int32_t c = lc[h];
-        uint32_t rank = 0;
-        for (uint32_t o = 0; o < H; ++o) {
-            const int32_t co = lc[o];
-            rank += (co > c || (co == c && o < h)) ? 1u : 0u;
-        }
-        if (rank < K) sel[rank] = h;  // ranks are a permutation: every slot < min(K,H) is written exactly once
+    const uint32_t h = blockIdx.x * 64u + threadIdx.x;
+    if (h >= H) return;
+    const int32_t c = lc[h];
+    uint32_t rank = 0;
+    for (uint32_t o = 0; o < H; ++o) {
+        const int32_t co = lc[o];  // same address in every lane: LDS broadcast
+        rank += (co > c || (co == c && o < h)) ? 1u : 0u;
     }
+    if (rank < K) sel[rank] = h;  // ranks are a permutation: every slot < min(K,H) is written exactly once
 }
 
 // lane <-> point, few hypotheses (K <= 64) staged in LDS: the inlier test's v_cmp result IS the wave
@@ -541,13 +542,13 @@ void launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels
     if (model == 0) {
         hipLaunchKernelGGL(k_score<0>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
                            (const float2 *)band, H, (float)tau, (uint32_t)kPreStride, counts);
-        hipLaunchKernelGGL(k_select_topk, dim3(1), dim3(1024), sizeof(int32_t) * H, s, (const int32_t *)counts, H, K, sel);
+        hipLaunchKernelGGL(k_select_topk, dim3((H + 63) / 64), dim3(64), sizeof(int32_t) * H, s, (const int32_t *)counts, H, K, sel);
         hipLaunchKernelGGL(k_score_few<0>, dim3(nbf), dim3(256), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
                            (const float2 *)band, (const uint32_t *)sel, K, (float)tau, counts_k);
     } else {
         hipLaunchKernelGGL(k_score<1>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
                            (const float2 *)band, H, (float)tau, (uint32_t)kPreStride, counts);
-        hipLaunchKernelGGL(k_select_topk, dim3(1), dim3(1024), sizeof(int32_t) * H, s, (const int32_t *)counts, H, K, sel);
+        hipLaunchKernelGGL(k_select_topk, dim3((H + 63) / 64), dim3(64), sizeof(int32_t) * H, s, (const int32_t *)counts, H, K, sel);
         hipLaunchKernelGGL(k_score_few<1>, dim3(nbf), dim3(256), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
                            (const float2 *)band, (const uint32_t *)sel, K, (float)tau, counts_k);
     }
