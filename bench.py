@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--radius", type=float, default=None, help="default: fixed-k 0.5*sqrt(50000/points)")
     ap.add_argument("--mode", choices=("frames", "slab"), default="frames")
-    ap.add_argument("--slots", type=int, default=2, help="frames in flight per GPU (HIP streams)")
+    ap.add_argument("--slots", type=int, default=3, help="frames in flight per GPU (HIP streams)")
     ap.add_argument("--ransac", type=int, default=1,
                     help="1: the step includes ONE RANSAC model (cylinder, H=1024: BASELINE configs[1]); 0: reference-faithful path only")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra reference-faithful / host-input legs")

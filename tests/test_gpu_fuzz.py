@@ -1,0 +1,98 @@
+"""Seeded randomised GPU-vs-oracle sweep over the parameter space (bound, radius, leaf, weighting
+factor, cloud shape/size, PointCloud2 layout), including the corners a fixed test forgets: radius
+larger than the box, radius tiny against the box (grid clamps), leaf larger than the box, clouds
+with duplicates / collinear runs / a single point, slabs of NaN rows.
+
+Integer outputs must match exactly; float outputs to the tolerances of tests/test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+from geometric_mapping_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def ang(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    s = np.linalg.norm(np.cross(a, b), axis=-1) / np.maximum(np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1), 1e-300)
+    return np.arcsin(np.clip(s, 0, 1))
+
+
+def make_cloud(rng, kind, n):
+    if kind == "tunnel":
+        return synth.tunnel_frame(n, seed=int(rng.integers(1 << 30)), radius=float(rng.uniform(0.5, 3.0)),
+                                  length=float(rng.uniform(2, 14)), sigma=float(rng.uniform(0, 0.03)),
+                                  axis=tuple(rng.normal(size=3)), floor_z=(-1.0 if rng.random() < 0.3 else None),
+                                  outlier_frac=float(rng.choice([0, 0.01, 0.1])))
+    if kind == "blob":
+        return rng.normal(0, rng.uniform(0.2, 3.0), (n, 3)).astype(np.float32)
+    if kind == "uniform":
+        return rng.uniform(-6, 6, (n, 3)).astype(np.float32)
+    if kind == "plane":
+        return synth.plane_patch(n, seed=int(rng.integers(1 << 30)), normal=tuple(rng.normal(size=3)), offset=float(rng.uniform(-2, 2)), half=4.0,
+                                 sigma=float(rng.choice([0, 0.01])))
+    if kind == "dupes":       # heavy duplication + a collinear run
+        base = rng.uniform(-2, 2, (max(n // 10, 1), 3)).astype(np.float32)
+        pts = base[rng.integers(len(base), size=n)]
+        t = np.linspace(-1, 1, 50, dtype=np.float32)
+        return np.vstack([pts, np.stack([t, t * 0.5, t * 0 + 1], axis=1)]).astype(np.float32)
+    raise ValueError(kind)
+
+
+CASES = list(range(28))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_random_frame_matches_oracle(gm, oc, case):
+    from geometric_mapping_amd import _lib
+    rng = np.random.default_rng(1000 + case)
+    kind = ["tunnel", "blob", "uniform", "plane", "dupes"][case % 5]
+    n = int(rng.choice([1, 2, 3, 7, 64, 65, 1000, 2047, 2048, 2049, 5000, 20000]))
+    xyz = make_cloud(rng, kind, n)
+    if rng.random() < 0.3 and len(xyz) > 10:   # slab of invalid rows in the middle
+        k = len(xyz) // 3
+        xyz[k:k + 5] = [np.nan, 0, 0]
+        xyz[k + 5:k + 8] = [np.inf, 1, -np.inf]
+    bound = float(rng.choice([0.5, 2.0, 5.0, 20.0]))
+    radius = float(rng.choice([0.001, 0.05, 0.3, 0.5, 1.5, 12.0]))
+    leaf = float(rng.choice([0.02, 0.1, 0.5, 3.0, 50.0]))
+    wf = float(rng.choice([0.1, 0.2, 0.3, -0.2]))
+    # bound the oracle's cost: huge radius on many points is O(n^2)
+    if radius >= 1.5 and len(xyz) > 5000:
+        xyz = xyz[:5000]
+    step, offs = [(12, (0, 4, 8)), (16, (0, 4, 8)), (32, (8, 12, 16)), (22, (2, 6, 10))][case % 4]
+    rows = synth.to_pointcloud2(xyz, point_step=step, offsets=offs, fill=0x5A)
+    with gm.GeometricMapping(boxFilterBound=bound, voxelGridLeafSize=leaf, neighborRadius=radius, weightingFactor=wf,
+                             flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_KEEP_COUNTS) as c:
+        res = c.process_frame(c.cloud_from_rows(rows, len(xyz), step, offs))
+        cloud, crows = c.cropped_cloud()
+        nrm = c.normals()
+        cnt = c.neighbor_counts()
+        cen, vcnt = c.voxel_centroids()
+    keep = oc.crop_box(xyz, bound)
+    o_n, o_cnt = oc.normals(xyz[keep], radius, oc.F64)
+    assert res["n_cropped"] == len(keep)
+    assert np.array_equal(cnt, o_cnt), (kind, n, bound, radius)          # neighbour sets, every point
+    # NaN-normal removal: identical except where the covariance is rank deficient (collinear / coincident
+    # neighbours): there PCL itself divides a rounding-noise cross product, so only well-posed points are pinned
+    valid = oc.finite_normals(o_n)
+    o = oc.process_frame(xyz, bound, radius, leaf, wf, oc.F64)
+    if kind != "dupes":
+        assert np.array_equal(crows, keep[valid]) and np.array_equal(cloud, xyz[keep][valid])
+        assert res["n_valid"] == o["n_valid"] and res["n_voxels"] == o["n_voxels"]
+        if len(cen):
+            assert np.array_equal(vcnt.sum(), res["n_valid"])
+            assert np.abs(cen - o["voxels"]).max() < 2e-6 * max(1.0, bound)
+        if len(nrm):
+            a = ang(nrm[:, :3], o["normals"][:, :3])
+            well = o_cnt[valid] >= 8
+            if well.any():
+                assert np.quantile(a[well], 0.98) < 2e-5, (kind, n, radius)
+        M = o["M"]
+        if np.abs(M).max() > 0:
+            assert np.abs(res["scatter"] - M).max() / np.abs(M).max() < 2e-4
+    else:
+        assert set(crows.tolist()) <= set(keep.tolist()) and np.all(np.diff(crows) > 0)
+    assert np.isfinite(res["eigenvalues"]).all() and np.isfinite(res["eigenvectors"]).all()
+    assert np.all(np.diff(res["eigenvalues"]) >= -1e-3 * max(1.0, abs(res["eigenvalues"][2])))
