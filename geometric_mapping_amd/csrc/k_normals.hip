@@ -261,6 +261,15 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
         const int ql = lane & (kTileQ - 1), part = lane / kTileQ;
         const bool active = (uint32_t)ql < qn && part == 0;
         const float4 q = spts4[qs + ((uint32_t)ql < qn ? ql : 0)];
+        // slab sharding: a tile made only of halo points (outside this rank's x range) produces no output
+        if (__ballot((uint32_t)ql < qn && q.x >= vd.own_lo && q.x < vd.own_hi) == 0) {
+            if (active) {
+                const float nanv = __builtin_nanf("");
+                normals4[__float_as_uint(q.w)] = make_float4(nanv, nanv, nanv, nanv);
+                if (counts) counts[__float_as_uint(q.w)] = 0;
+            }
+            continue;
+        }
 
         double Sn = 0, Sx = 0, Sy = 0, Sz = 0, Sxx = 0, Sxy = 0, Sxz = 0, Syy = 0, Syz = 0, Szz = 0;
         const v2f qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
