@@ -48,8 +48,11 @@ __device__ __forceinline__ v2f pk_add_rn(v2f a, v2f b)
 }
 
 constexpr int kNrThreads = 256;
-constexpr int kSplit = 1;                 // lanes per query: each handles 1/kSplit of the tile's candidates
-constexpr int kTileQ = kWave / kSplit;    // queries per tile
+constexpr int kTileQ = kWave;             // queries per tile: one per lane
+constexpr int kGroups = 4;                // lane groups with their own candidate window
+constexpr int kGroupLanes = kWave / kGroups;
+constexpr int kWinCap = 256;              // candidates staged per chunk of one row range (4 x 16 B per lane in flight)
+constexpr int kWinPad = 16;               // far-away padding behind a chunk (alignment + last partial group)
 constexpr int kTileSpan = 3;              // max x extent of one tile, in (coarse) cell edges
 constexpr int kNrWaves = kNrThreads / kWave;
 
@@ -192,7 +195,8 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
 {
     // candidate window, one per wave, SoA so that one broadcast ds_read_b128 feeds
     // the x (or y, z) of FOUR candidates to every lane
-    __shared__ __attribute__((aligned(16))) float win[kNrWaves][3][kWave];
+    __shared__ __attribute__((aligned(16))) float win[kNrWaves][3][kWinCap + kWinPad];
+    __shared__ double tot[kNrWaves][10][kWave];  // per-lane fp64 moment totals of the current tile
     const int lane = lane_id();
     const int w = threadIdx.x / kWave;
     const uint32_t n = ctr->n_cropped;
@@ -225,44 +229,18 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
             qn = (~mask == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~mask);  // same-group lanes are contiguous from lane 0
         }
 
-        // tile geometry: one x-row, cells [cxa, cxb]
-        const uint32_t kb = skeys[qs + qn - 1];
+        // tile geometry: one x-row
         const uint32_t row = ka / (uint32_t)g.nx;
-        const int cxa = (int)(ka - row * (uint32_t)g.nx), cxb = (int)(kb - row * (uint32_t)g.nx);
         const int cy = (int)(row % (uint32_t)g.ny), cz = (int)(row / (uint32_t)g.ny);
-        // x-rows are sorted by fine x cell: candidates are exactly the points within `xreach` fine cells (>= r)
-        const int x0 = cxa > g.xreach ? cxa - g.xreach : 0, x1 = cxb + g.xreach < g.nx - 1 ? cxb + g.xreach : g.nx - 1;
 
-        // 9 candidate ranges (one per neighbouring x-row); lanes 0..8 find begin,
-        // lanes 16..24 find end, by binary search in the sorted keys
-        uint32_t bound = 0;
-        {
-            const int r = lane & 15;
-            if (r < 9 && (lane < 9 || (lane >= 16 && lane < 25))) {
-                const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
-                if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-                    const uint32_t rb = (uint32_t)((zz * g.ny + yy) * g.nx);
-                    bound = (lane < 16) ? lower_bound_u32(skeys, n, rb + (uint32_t)x0)
-                                        : lower_bound_u32(skeys, n, rb + (uint32_t)x1 + 1u);
-                }
-            }
-        }
-        uint32_t rbeg[9], rpre[10];
-        rpre[0] = 0;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            const uint32_t b = __shfl(bound, r, kWave), e = __shfl(bound, 16 + r, kWave);
-            rbeg[r] = b;
-            rpre[r + 1] = rpre[r] + (e - b);  // invalid rows: b == e == 0
-        }
-        const uint32_t total = rpre[9];
-
-        // this lane's query: kSplit lanes share a query, lane part p takes candidate groups p, p+kSplit, ...
-        const int ql = lane & (kTileQ - 1), part = lane / kTileQ;
-        const bool active = (uint32_t)ql < qn && part == 0;
-        const float4 q = spts4[qs + ((uint32_t)ql < qn ? ql : 0)];
+        // this lane's query and its fine x cell (keys inside a tile are ascending: lanes are x-sorted)
+        const int ql = lane;
+        const bool active = (uint32_t)ql < qn;
+        const uint32_t qidx = qs + (active ? (uint32_t)ql : qn - 1u);
+        const float4 q = spts4[qidx];
+        const int fxl = (int)(skeys[qidx] - row * (uint32_t)g.nx);
         // slab sharding: a tile made only of halo points (outside this rank's x range) produces no output
-        if (__ballot((uint32_t)ql < qn && q.x >= vd.own_lo && q.x < vd.own_hi) == 0) {
+        if (__ballot(active && q.x >= vd.own_lo && q.x < vd.own_hi) == 0) {
             if (active) {
                 const float nanv = __builtin_nanf("");
                 normals4[__float_as_uint(q.w)] = make_float4(nanv, nanv, nanv, nanv);
@@ -271,53 +249,119 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
             continue;
         }
 
-        double Sn = 0, Sx = 0, Sy = 0, Sz = 0, Sxx = 0, Sxy = 0, Sxz = 0, Syy = 0, Syz = 0, Szz = 0;
+        // ---- candidate windows.  The 3x3 neighbouring x-rows are x-sorted runs of the sorted cloud.  The
+        // wave is cut into kGroups lane groups (x-sorted, so each covers a short x interval); group gi only
+        // needs the candidates of a row whose fine x cell lies within xreach of ITS interval.  All groups
+        // walk their own window in lock-step (different LDS addresses, broadcast inside a group), so the
+        // loop runs for the longest group window (~2.4 cell edges) instead of the tile's (~3.4).
+        const int gi = lane / kGroupLanes;  // (inactive lanes repeat the tile's last query, so group intervals stay valid)
+        // 9 rows x kGroups groups x {begin,end}: binary searches in the sorted keys, spread over the lanes
+        uint32_t sres[2] = {0, 0};
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            const int i = lane + rnd * kWave;       // slot i = kind*36 + r*4 + group   (kGroups == 4)
+            const bool work = i < 2 * 9 * kGroups;
+            const int ii = work ? i : 0;
+            const int kind = ii / (9 * kGroups), rem = ii % (9 * kGroups), r = rem / kGroups, gg = rem % kGroups;
+            // x interval of lane group gg (shuffles run with every lane active)
+            const int lo_fx = __shfl(fxl, gg * kGroupLanes, kWave);
+            const int hi_fx = __shfl(fxl, gg * kGroupLanes + kGroupLanes - 1, kWave);
+            const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
+            if (work && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                const uint32_t rbk = (uint32_t)((zz * g.ny + yy) * g.nx);
+                const int xa = lo_fx > g.xreach ? lo_fx - g.xreach : 0;
+                const int xb = hi_fx + g.xreach < g.nx - 1 ? hi_fx + g.xreach : g.nx - 1;
+                sres[rnd] = kind == 0 ? lower_bound_u32(skeys, n, rbk + (uint32_t)xa)
+                                      : lower_bound_u32(skeys, n, rbk + (uint32_t)xb + 1u);
+            }
+        }
+
+        // fp64 totals live in LDS (one 8-byte slot per lane and moment): 20 VGPRs less keeps 4 waves per SIMD
+        double *T = &tot[w][0][lane];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) T[k * kWave] = 0.0;
         const v2f qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
         const v2f r2v = {g.r2, g.r2};
-        const float *wx = &win[w][0][0], *wy = &win[w][1][0], *wz = &win[w][2][0];
-
-        // candidate fetch for window v0: flattened candidate index -> its range -> sorted array
-        auto fetch = [&](uint32_t v0) -> float4 {
-            const uint32_t vv = v0 + lane;
-            float4 cpv = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);  // never within r of anything
-            if (vv < total) {
-                uint32_t src = rbeg[0] + vv;
-#pragma unroll
-                for (int r = 1; r < 9; ++r)
-                    if (vv >= rpre[r]) src = rbeg[r] + (vv - rpre[r]);
-                cpv = spts4[src];
-            }
-            return cpv;
+        float *wx = &win[w][0][0], *wy = &win[w][1][0], *wz = &win[w][2][0];
+        v2f sn = {0, 0}, sx = {0, 0}, sy = {0, 0}, sz = {0, 0}, sxx = {0, 0}, sxy = {0, 0}, sxz = {0, 0},
+            syy = {0, 0}, syz = {0, 0}, szz = {0, 0};
+        int since_fold = 0;
+        auto fold = [&]() {  // fp32 partial sums -> fp64 totals
+            T[0 * kWave] += (double)(sn.x + sn.y);
+            T[1 * kWave] += (double)sx.x + (double)sx.y; T[2 * kWave] += (double)sy.x + (double)sy.y;
+            T[3 * kWave] += (double)sz.x + (double)sz.y;
+            T[4 * kWave] += (double)sxx.x + (double)sxx.y; T[5 * kWave] += (double)sxy.x + (double)sxy.y;
+            T[6 * kWave] += (double)sxz.x + (double)sxz.y; T[7 * kWave] += (double)syy.x + (double)syy.y;
+            T[8 * kWave] += (double)syz.x + (double)syz.y; T[9 * kWave] += (double)szz.x + (double)szz.y;
+            sn = (v2f){0, 0}; sx = sn; sy = sn; sz = sn; sxx = sn; sxy = sn; sxz = sn; syy = sn; syz = sn; szz = sn;
+            since_fold = 0;
         };
-        float4 cp_next = fetch(0);
-        for (uint32_t v0 = 0; v0 < total; v0 += kWave) {
-            const float4 cp = cp_next;
-            wave_lds_fence();  // previous window fully consumed
-            win[w][0][lane] = cp.x; win[w][1][lane] = cp.y; win[w][2][lane] = cp.z;
+
+        // ---- chunk iterator over the 9 row ranges (row-wide range = begin of the lowest-x group .. end of
+        // the highest-x group), software-pipelined: the global loads of chunk i+1 are in flight (in registers)
+        // while chunk i is consumed from LDS
+        auto row_begin = [&](int r) -> uint32_t { return __builtin_amdgcn_readlane(sres[0], r * kGroups); };
+        auto row_end = [&](int r) -> uint32_t {
+            const int je = 9 * kGroups + r * kGroups + (kGroups - 1);
+            return je < kWave ? __builtin_amdgcn_readlane(sres[0], je) : __builtin_amdgcn_readlane(sres[1], je - kWave);
+        };
+        int nr = 0;                       // next chunk: row index, start, length (0 = none left)
+        uint32_t nc0 = 0, nlen = 0;
+        auto seek = [&](int r, uint32_t c) {  // first non-empty chunk at or after (r, c)
+            nlen = 0;
+            while (r < 9) {
+                const uint32_t e = row_end(r);
+                if (c < e) { nr = r; nc0 = c; nlen = (e - c < (uint32_t)kWinCap) ? e - c : (uint32_t)kWinCap; return; }
+                ++r;
+                if (r < 9) c = row_begin(r);
+            }
+        };
+        if (lane < kWinPad) { wx[kWinCap + lane] = 3.0e18f; wy[kWinCap + lane] = 3.0e18f; wz[kWinCap + lane] = 3.0e18f; }
+        seek(0, row_begin(0));
+        while (nlen) {
+            const int r = nr;
+            const uint32_t c0 = nc0, clen = nlen;
+            // stage the chunk (coalesced 16 B loads) plus far-away padding right behind it
+            wave_lds_fence();  // previous chunk fully consumed
+#pragma unroll
+            for (int k = 0; k < kWinCap / kWave; ++k) {
+                const uint32_t i = (uint32_t)lane + (uint32_t)k * kWave;
+                if (i < clen + kWinPad) {
+                    float4 cp = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);  // never within r of anything
+                    if (i < clen) cp = spts4[c0 + i];
+                    wx[i] = cp.x; wy[i] = cp.y; wz[i] = cp.z;
+                }
+            }
             wave_lds_fence();
-            cp_next = fetch(v0 + kWave);  // in flight while this window is consumed
-            const int m = (total - v0 < (uint32_t)kWave) ? (int)(total - v0) : kWave;
-            const int groups = ((m + 3) >> 2) + (kSplit - 1);  // padding slots hold far-away points
-            const int iters = groups / kSplit;
-            // branch-free, two candidates per packed instruction (v_pk_*_f32): the
-            // inlier test becomes a 0/1 weight so nothing in the loop touches EXEC
-            v2f sn = {0, 0}, sx = {0, 0}, sy = {0, 0}, sz = {0, 0}, sxx = {0, 0}, sxy = {0, 0}, sxz = {0, 0},
-                syy = {0, 0}, syz = {0, 0}, szz = {0, 0};
-            // lanes of one part read the same address (LDS broadcast); parts read neighbouring groups
-            float4 nx4 = *reinterpret_cast<const float4 *>(wx + 4 * part), ny4 = *reinterpret_cast<const float4 *>(wy + 4 * part),
-                   nz4 = *reinterpret_cast<const float4 *>(wz + 4 * part);
-            for (int gidx = 0; gidx < iters; ++gidx) {
-                const float4 cx4 = nx4, cy4 = ny4, cz4 = nz4;
-                const int nj = (gidx + 1 < iters) ? ((gidx + 1) * kSplit + part) * 4 : 0;  // prefetch the next group
-                nx4 = *reinterpret_cast<const float4 *>(wx + nj);
-                ny4 = *reinterpret_cast<const float4 *>(wy + nj);
-                nz4 = *reinterpret_cast<const float4 *>(wz + nj);
+            if (c0 + clen < row_end(r)) seek(r, c0 + clen); else seek(r + 1, r + 1 < 9 ? row_begin(r + 1) : 0u);
+            // my group's window inside this chunk (clamped), start aligned down to 4 for ds_read_b128
+            const int sb_slot = r * kGroups + gi, se_slot = 9 * kGroups + r * kGroups + gi;
+            const uint32_t mb = __shfl(sres[0], sb_slot, kWave);
+            const uint32_t me_a = __shfl(sres[0], se_slot & (kWave - 1), kWave), me_b = __shfl(sres[1], se_slot & (kWave - 1), kWave);
+            const uint32_t me = se_slot < kWave ? me_a : me_b;
+            uint32_t ob = mb > c0 ? mb - c0 : 0u, oe = me > c0 ? me - c0 : 0u;
+            if (ob > clen) ob = clen;
+            if (oe > clen) oe = clen;
+            ob &= ~3u;
+            const uint32_t mylen = oe > ob ? oe - ob : 0u;
+            uint32_t maxlen = mylen;  // longest group window of the wave (wave-uniform trip count)
+#pragma unroll
+            for (int o = kGroupLanes; o < kWave; o <<= 1) {
+                const uint32_t t2 = __shfl_xor(maxlen, o, kWave);
+                maxlen = maxlen > t2 ? maxlen : t2;
+            }
+            maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+            const int iters = (int)((maxlen + 3u) >> 2);
+            // a group whose window is shorter than the longest one keeps reading: first real candidates of
+            // the row beyond its window (they fail the distance test), then the far padding behind the chunk
+            const uint32_t lim = (clen + 3u) & ~3u;  // first all-padding group of four
+            auto four = [&](const float4 cx4, const float4 cy4, const float4 cz4) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const v2f cx = h ? (v2f){cx4.z, cx4.w} : (v2f){cx4.x, cx4.y};
-                    const v2f cy = h ? (v2f){cy4.z, cy4.w} : (v2f){cy4.x, cy4.y};
-                    const v2f cz = h ? (v2f){cz4.z, cz4.w} : (v2f){cz4.x, cz4.y};
-                    const v2f dx = cx - qx, dy = cy - qy, dz = cz - qz;
+                    const v2f cy2 = h ? (v2f){cy4.z, cy4.w} : (v2f){cy4.x, cy4.y};
+                    const v2f cz2 = h ? (v2f){cz4.z, cz4.w} : (v2f){cz4.x, cz4.y};
+                    const v2f dx = cx - qx, dy = cy2 - qy, dz = cz2 - qz;
                     // FLANN L2_Simple: every product and sum rounded, in this order
                     const v2f xx = pk_mul_rn(dx, dx), yy = pk_mul_rn(dy, dy), zz = pk_mul_rn(dz, dz);
                     const v2f d2 = pk_add_rn(pk_add_rn(xx, yy), zz);
@@ -329,20 +373,26 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
                     sxx += mx * dx; syy += my * dy; szz += mz * dz;
                     sxy += mx * dy; sxz += mx * dz; syz += my * dz;
                 }
+            };
+            // two groups of four candidates per trip: all six LDS reads are issued before the first group is
+            // consumed, so the second group's latency hides behind the first group's arithmetic
+            for (int it = 0; it < iters; it += 2) {
+                uint32_t a0 = ob + 4u * (uint32_t)it, a1 = a0 + 4u;
+                a0 = a0 < lim ? a0 : lim;
+                a1 = a1 < lim ? a1 : lim;   // (an odd trip count reads one extra group: real or far points, harmless)
+                const float4 x0 = *reinterpret_cast<const float4 *>(wx + a0), y0 = *reinterpret_cast<const float4 *>(wy + a0),
+                             z0 = *reinterpret_cast<const float4 *>(wz + a0);
+                const float4 x1 = *reinterpret_cast<const float4 *>(wx + a1), y1 = *reinterpret_cast<const float4 *>(wy + a1),
+                             z1 = *reinterpret_cast<const float4 *>(wz + a1);
+                four(x0, y0, z0);
+                four(x1, y1, z1);
+                since_fold += 2;
+                if (since_fold >= 16) fold();  // every 64 candidates
             }
-            // fold this window's fp32 partial sums into the fp64 totals
-            Sn += (double)(sn.x + sn.y);
-            Sx += (double)sx.x + (double)sx.y; Sy += (double)sy.x + (double)sy.y; Sz += (double)sz.x + (double)sz.y;
-            Sxx += (double)sxx.x + (double)sxx.y; Sxy += (double)sxy.x + (double)sxy.y;
-            Sxz += (double)sxz.x + (double)sxz.y; Syy += (double)syy.x + (double)syy.y;
-            Syz += (double)syz.x + (double)syz.y; Szz += (double)szz.x + (double)szz.y;
         }
-        if (kSplit == 2) {  // join the two halves of every query's sums
-            Sn += __shfl_xor(Sn, 32, kWave);
-            Sx += __shfl_xor(Sx, 32, kWave); Sy += __shfl_xor(Sy, 32, kWave); Sz += __shfl_xor(Sz, 32, kWave);
-            Sxx += __shfl_xor(Sxx, 32, kWave); Sxy += __shfl_xor(Sxy, 32, kWave); Sxz += __shfl_xor(Sxz, 32, kWave);
-            Syy += __shfl_xor(Syy, 32, kWave); Syz += __shfl_xor(Syz, 32, kWave); Szz += __shfl_xor(Szz, 32, kWave);
-        }
+        fold();
+        const double Sn = T[0 * kWave], Sx = T[1 * kWave], Sy = T[2 * kWave], Sz = T[3 * kWave], Sxx = T[4 * kWave],
+                     Sxy = T[5 * kWave], Sxz = T[6 * kWave], Syy = T[7 * kWave], Syz = T[8 * kWave], Szz = T[9 * kWave];
         const int cnt = (int)Sn;
 
         bool vox_ok = false;
