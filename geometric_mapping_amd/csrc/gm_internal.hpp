@@ -104,7 +104,7 @@ void launch_exclusive_scan(uint32_t *data, uint32_t count, uint32_t *total_out, 
 uint32_t radix_hist_entries(uint32_t n_cap);
 // k_normals.hip
 void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, uint32_t n_cap, bool keep_counts,
-                             hipStream_t s);
+                             bool concurrent, hipStream_t s);
 uint32_t max_tiles(uint32_t n_cap, const GridParams &g);
 // k_frame.hip
 void launch_compact_valid(Slot &sl, uint32_t n_cap, float own_lo, float own_hi, hipStream_t s);
