@@ -393,24 +393,28 @@ gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap)
     const uint32_t H = cf.ransac_hypotheses;
     hipStream_t s = sl.stream;
     const uint32_t *n_ptr = &sl.ctr->n_valid;
-    GM_HIP(ctx, hipMemsetAsync(sl.labels, 0, n_cap ? n_cap : 1, s));
-    GM_HIP(ctx, hipMemsetAsync(sl.best_plane, 0xFF, 8, s));
-    GM_HIP(ctx, hipMemsetAsync(sl.best_cyl, 0xFF, 8, s));
+    // the first model of the frame sees every point (labels == nullptr) and its label pass writes the whole
+    // label array, so no memset is needed; best_* are always written by the arg-max kernels
+    bool first = true;
     if (do_plane) {
-        launch_plane_hypotheses(sl.valid4, sl.labels, 0, n_ptr, n_cap, cf.ransac_seed, H, sl.hyp_plane, s);
-        launch_score_preemptive(0, sl.valid4, sl.labels, 0, n_ptr, n_cap, sl.hyp_plane, sl.band, H, cf.ransac_threshold,
+        uint8_t *lab = first ? nullptr : sl.labels;
+        launch_plane_hypotheses(sl.valid4, lab, 0, n_ptr, n_cap, cf.ransac_seed, H, sl.hyp_plane, s);
+        launch_score_preemptive(0, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_plane, sl.band, H, cf.ransac_threshold,
                                 sl.score_partial, sl.cnt_plane, sl.best_plane, s);
         launch_label(0, sl.valid4, sl.labels, 0, 1, n_ptr, n_cap, sl.hyp_plane, sl.band, sl.best_plane,
-                     cf.ransac_threshold, s);
+                     cf.ransac_threshold, first ? 1 : 0, s);
         launch_segment_moments(sl.valid4, sl.vnorm4, sl.labels, 1, n_ptr, n_cap, sl.mom_partial, sl.mom_plane, s);
+        first = false;
     }
     if (do_cyl) {
-        launch_cylinder_hypotheses(sl.valid4, sl.vnorm4, sl.labels, 0, n_ptr, n_cap, cf.ransac_seed + 1, H, sl.hyp_cyl, s);
-        launch_score_preemptive(1, sl.valid4, sl.labels, 0, n_ptr, n_cap, sl.hyp_cyl, sl.band, H, cf.ransac_threshold,
+        uint8_t *lab = first ? nullptr : sl.labels;
+        launch_cylinder_hypotheses(sl.valid4, sl.vnorm4, lab, 0, n_ptr, n_cap, cf.ransac_seed + 1, H, sl.hyp_cyl, s);
+        launch_score_preemptive(1, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_cyl, sl.band, H, cf.ransac_threshold,
                                 sl.score_partial, sl.cnt_cyl, sl.best_cyl, s);
         launch_label(1, sl.valid4, sl.labels, 0, 2, n_ptr, n_cap, sl.hyp_cyl, sl.band, sl.best_cyl,
-                     cf.ransac_threshold, s);
+                     cf.ransac_threshold, first ? 1 : 0, s);
         launch_segment_moments(sl.valid4, sl.vnorm4, sl.labels, 2, n_ptr, n_cap, sl.mom_partial, sl.mom_cyl, s);
+        first = false;
     }
     launch_ext_finalize(sl.hyp_plane, do_plane ? sl.best_plane : nullptr, sl.hyp_cyl, do_cyl ? sl.best_cyl : nullptr,
                         sl.mom_plane, sl.mom_cyl, &sl.d_out->ext, s);
@@ -422,6 +426,15 @@ gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap)
 extern "C" {
 
 uint32_t gm_abi_version(void) { return GM_ABI_VERSION; }
+
+#ifdef GM_NORMALS_STATS
+// diagnostic builds only: raw device counters of a slot (16 words)
+extern "C" int gm_debug_counters(gm_ctx *ctx, uint32_t slot, uint32_t *out)
+{
+    hipDeviceSynchronize();
+    return (int)hipMemcpy(out, ctx->slots[slot].ctr, sizeof(gm::DevCounters), hipMemcpyDeviceToHost);
+}
+#endif
 
 const char *gm_status_string(gm_status s)
 {

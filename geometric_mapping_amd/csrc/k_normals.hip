@@ -49,11 +49,28 @@ __device__ __forceinline__ v2f pk_add_rn(v2f a, v2f b)
     return r;
 }
 
+// 1.0 where d2 < r2 (strictly), else 0.0, for both halves in ONE VALU op: clamp01(fma(d2, -2^100, r2 * 2^100)).
+// The fma rounds 2^100 * (r2 - d2) once, so its sign is exact and it is zero only when d2 == r2; any positive
+// value is >= 2^100 * ulp >> 1 and clamps to 1, overflow to -inf clamps to 0.  (v_cmp + v_cndmask per half costs
+// four issue slots and a VALU->SGPR hazard.)
+__device__ __forceinline__ v2f pk_within(v2f d2, v2f neg_big, v2f r2_big)
+{
+    v2f w;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(w) : "v"(d2), "v"(neg_big), "v"(r2_big));
+    return w;
+}
+
 constexpr int kNrThreads = 256;
 constexpr int kTileQ = kWave;             // queries per tile: one per lane
 constexpr int kGroups = 4;                // lane groups with their own candidate window
 constexpr int kGroupLanes = kWave / kGroups;
-constexpr int kWinCap = 256;              // candidates staged per chunk of one row range (4 x 16 B per lane in flight)
+#ifndef GM_FOLD_TRIPS
+#define GM_FOLD_TRIPS 16  // groups of four candidates between two folds of the fp32 partial sums into fp64
+#endif
+#ifndef GM_WINCAP
+#define GM_WINCAP 320
+#endif
+constexpr int kWinCap = GM_WINCAP;              // candidates staged per chunk of one row range (4 x 16 B per lane in flight)
 constexpr int kWinPad = 16;               // far-away padding behind a chunk (alignment + last partial group)
 constexpr int kTileSpan = 3;              // max x extent of one tile, in (coarse) cell edges
 constexpr int kNrWaves = kNrThreads / kWave;
@@ -286,18 +303,21 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
 #pragma unroll
         for (int k = 0; k < 10; ++k) T[k * kWave] = 0.0;
         const v2f qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
-        const v2f r2v = {g.r2, g.r2};
+        const float big = 0x1p100f;
+        const v2f neg_big = {-big, -big}, r2_big = {g.r2 * big, g.r2 * big};  // exact scalings
         float *wx = &win[w][0][0], *wy = &win[w][1][0], *wz = &win[w][2][0];
         v2f sn = {0, 0}, sx = {0, 0}, sy = {0, 0}, sz = {0, 0}, sxx = {0, 0}, sxy = {0, 0}, sxz = {0, 0},
             syy = {0, 0}, syz = {0, 0}, szz = {0, 0};
         int since_fold = 0;
         auto fold = [&]() {  // fp32 partial sums -> fp64 totals
+            // (the two halves are first joined in fp32: one more rounding of a <= 64-term partial sum, then one
+            // conversion and one fp64 add per moment)
             T[0 * kWave] += (double)(sn.x + sn.y);
-            T[1 * kWave] += (double)sx.x + (double)sx.y; T[2 * kWave] += (double)sy.x + (double)sy.y;
-            T[3 * kWave] += (double)sz.x + (double)sz.y;
-            T[4 * kWave] += (double)sxx.x + (double)sxx.y; T[5 * kWave] += (double)sxy.x + (double)sxy.y;
-            T[6 * kWave] += (double)sxz.x + (double)sxz.y; T[7 * kWave] += (double)syy.x + (double)syy.y;
-            T[8 * kWave] += (double)syz.x + (double)syz.y; T[9 * kWave] += (double)szz.x + (double)szz.y;
+            T[1 * kWave] += (double)(sx.x + sx.y); T[2 * kWave] += (double)(sy.x + sy.y);
+            T[3 * kWave] += (double)(sz.x + sz.y);
+            T[4 * kWave] += (double)(sxx.x + sxx.y); T[5 * kWave] += (double)(sxy.x + sxy.y);
+            T[6 * kWave] += (double)(sxz.x + sxz.y); T[7 * kWave] += (double)(syy.x + syy.y);
+            T[8 * kWave] += (double)(syz.x + syz.y); T[9 * kWave] += (double)(szz.x + szz.y);
             sn = (v2f){0, 0}; sx = sn; sy = sn; sz = sn; sxx = sn; sxy = sn; sxz = sn; syy = sn; syz = sn; szz = sn;
             since_fold = 0;
         };
@@ -357,6 +377,17 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
             }
             maxlen = __builtin_amdgcn_readfirstlane(maxlen);
             const int iters = (int)((maxlen + 3u) >> 2);
+#ifdef GM_NORMALS_STATS  // diagnostic build only (tools/normals_stats.py): candidate-stream accounting
+            {
+                const uint32_t sum_len = (uint32_t)wave_sum((unsigned long long)mylen) / kGroupLanes;
+                if (lane == 0) {
+                    atomicAdd(&ctr->pad[0], (uint32_t)(((iters + 1) & ~1) * 4));  // wave-candidates streamed
+                    atomicAdd(&ctr->pad[1], sum_len);                              // sum of the 4 group windows
+                    atomicAdd(&ctr->pad[2], clen);                                 // candidates staged
+                    atomicAdd(&ctr->reserved0, 1u);                                // chunks
+                }
+            }
+#endif
             // a group whose window is shorter than the longest one keeps reading: first real candidates of
             // the row beyond its window (they fail the distance test), then the far padding behind the chunk
             const uint32_t lim = (clen + 3u) & ~3u;  // first all-padding group of four
@@ -371,11 +402,11 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
                     const v2f xx = pk_mul_rn(dx, dx), yy = pk_mul_rn(dy, dy), zz = pk_mul_rn(dz, dz);
                     const v2f d2 = pk_add_rn(pk_add_rn(xx, yy), zz);
                     // RadiusResultSet::addPoint: strict d2 < r2
-                    const v2f wgt = {d2.x < r2v.x ? 1.0f : 0.0f, d2.y < r2v.y ? 1.0f : 0.0f};
-                    const v2f mx = wgt * dx, my = wgt * dy, mz = wgt * dz;
+                    const v2f wgt = pk_within(d2, neg_big, r2_big);
+                    const v2f mx = wgt * dx, my = wgt * dy;
                     sn += wgt;
-                    sx += mx; sy += my; sz += mz;
-                    sxx += mx * dx; syy += my * dy; szz += mz * dz;
+                    sx += mx; sy += my; sz += wgt * dz;
+                    sxx += wgt * xx; syy += wgt * yy; szz += wgt * zz;  // the rounded squares of the predicate
                     sxy += mx * dy; sxz += mx * dz; syz += my * dz;
                 }
             };
@@ -392,7 +423,7 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
                 four(x0, y0, z0);
                 four(x1, y1, z1);
                 since_fold += 2;
-                if (since_fold >= 16) fold();  // every 64 candidates
+                if (since_fold >= GM_FOLD_TRIPS) fold();  // 16 trips = every 64 candidates (32 per packed half)
             }
         }
         fold();

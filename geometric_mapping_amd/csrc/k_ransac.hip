@@ -16,7 +16,7 @@
 //   s_bcnt1 counts it; per-block sums go through LDS, per-block rows to HBM with plain
 //   stores, and a second kernel sums the rows in fixed order and picks the arg-max.
 //   No float atomics anywhere: counts are integers, results are run-to-run identical.
-// (The paragraph above describes k_score_few; k_score, the H-wide scorer, maps lane <-> hypothesis.)
+// (k_score / k_score_sel, the scorers actually used, map lane <-> hypothesis: see their comments.)
 #include "gm_internal.hpp"
 
 namespace gm {
@@ -275,73 +275,84 @@ __global__ __launch_bounds__(1024) void k_best_hypothesis(const int32_t *__restr
 constexpr int kPreStride = 8;   // stage 1 scores every 8th point
 constexpr int kPreKeep = 64;    // stage 2 re-scores this many hypotheses on every point
 
-__global__ __launch_bounds__(64) void k_select_topk(const int32_t *__restrict__ counts, uint32_t H, uint32_t K,
-                                                    uint32_t *__restrict__ sel)
+__global__ __launch_bounds__(256) void k_select_topk(const int32_t *__restrict__ counts, uint32_t H, uint32_t K,
+                                                     uint32_t *__restrict__ sel, int32_t *__restrict__ counts_k)
 {
-    // one wave per 64 hypotheses, each lane ranks its hypothesis against all H counts (staged in LDS)
+    // 16 hypotheses per block, 16 lanes per hypothesis: every lane ranks its hypothesis against 1/16 of the
+    // counts (staged in LDS), a 4-step shuffle sum joins the partial ranks
     extern __shared__ int32_t lc[];  // [H]
-    for (uint32_t h = threadIdx.x; h < H; h += 64) lc[h] = counts[h];
+    for (uint32_t h = threadIdx.x; h < H; h += 256) lc[h] = counts[h];
+    if (blockIdx.x == 0 && threadIdx.x < K) counts_k[threadIdx.x] = 0;  // stage-2 counters start at zero
     __syncthreads();
-    const uint32_t h = blockIdx.x * 64u + threadIdx.x;
-    if (h >= H) return;
-    const int32_t c = lc[h];
+    const uint32_t h = blockIdx.x * 16u + threadIdx.x / 16u, part = threadIdx.x & 15u;
+    const int32_t c = h < H ? lc[h] : 0;
     uint32_t rank = 0;
-    for (uint32_t o = 0; o < H; ++o) {
-        const int32_t co = lc[o];  // same address in every lane: LDS broadcast
+    for (uint32_t o = part; o < H; o += 16u) {
+        const int32_t co = lc[o];
         rank += (co > c || (co == c && o < h)) ? 1u : 0u;
     }
-    if (rank < K) sel[rank] = h;  // ranks are a permutation: every slot < min(K,H) is written exactly once
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) rank += __shfl_xor(rank, o, kWave);
+    if (h < H && part == 0 && rank < K) sel[rank] = h;  // ranks are a permutation: slots < min(K,H) are written once
 }
 
-// lane <-> point, few hypotheses (K <= 64) staged in LDS: the inlier test's v_cmp result IS the wave
-// ballot, s_bcnt1 counts it, one LDS atomic per (wave, hypothesis), one global atomic per (block, hypothesis)
+// Stage 2: the K <= 64 selected hypotheses against every point.  Same shape as k_score: lane <-> selected
+// hypothesis (in registers), each of the block's 4 waves owns 256 points staged in LDS as SoA groups of four,
+// pure-VALU inner loop, LDS reduce over the waves, one integer atomicAdd per (block, hypothesis).
 template <int MODEL>
-__global__ __launch_bounds__(256) void k_score_few(const float4 *__restrict__ pts, const uint8_t *__restrict__ labels,
+__global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pts, const uint8_t *__restrict__ labels,
                                                    uint32_t want, const uint32_t *__restrict__ n_ptr, uint32_t n_host,
                                                    const float *__restrict__ hyp8, const float2 *__restrict__ band,
                                                    const uint32_t *__restrict__ sel, uint32_t K, float tau,
                                                    int32_t *__restrict__ counts_k)
 {
-    constexpr int P = 4;
-    __shared__ __attribute__((aligned(16))) float lh[kPreKeep][8];
-    __shared__ float2 lb[kPreKeep];
-    __shared__ uint32_t lcnt[kPreKeep];
+    constexpr int PTS = 256;  // per wave
+    __shared__ float4 lp[4][PTS / 4][3];
+    __shared__ float red[4][64];
     const uint32_t n = n_ptr ? *n_ptr : n_host;
-    const uint32_t base = blockIdx.x * 256u * P;
-    if (base >= n) return;  // uniform per block
-    for (uint32_t k = threadIdx.x; k < K * 8; k += 256) lh[k >> 3][k & 7] = hyp8[8 * (size_t)sel[k >> 3] + (k & 7)];
-    if (threadIdx.x < K) {
-        lcnt[threadIdx.x] = 0;
-        lb[threadIdx.x] = MODEL == 1 ? band[sel[threadIdx.x]] : make_float2(0.f, 0.f);
-    }
-    float px[P], py[P], pz[P];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t base = (blockIdx.x * 4u + wave) * PTS;
+    const uint32_t m = base >= n ? 0u : ((n - base < (uint32_t)PTS) ? n - base : (uint32_t)PTS);
+    const uint32_t groups = (m + 3u) >> 2;
+    if (blockIdx.x * 4u * PTS >= n) return;  // uniform per block
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const uint32_t i = base + p * 256u + threadIdx.x;
+    for (int p = 0; p < PTS / 64; ++p) {
+        const uint32_t j = p * 64 + lane;
+        const uint32_t i = base + j;
         bool ok = i < n;
         if (ok && labels) ok = labels[i] == want;
         float4 v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 0.f);
-        if (ok) v = pts[i];
-        px[p] = v.x; py[p] = v.y; pz[p] = v.z;
+        if (ok) v = pts[i];  // masked / out-of-range points are NaN: never an inlier
+        float *gp = reinterpret_cast<float *>(&lp[wave][j >> 2][0]);
+        gp[(j & 3)] = v.x; gp[4 + (j & 3)] = v.y; gp[8 + (j & 3)] = v.z;
     }
-    __syncthreads();
-    for (uint32_t k = 0; k < K; ++k) {
-        const float4 ha = *reinterpret_cast<const float4 *>(&lh[k][0]);
-        const float4 hb = *reinterpret_cast<const float4 *>(&lh[k][4]);
-        const float2 bd = lb[k];
-        uint32_t c = 0;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const bool in = MODEL == 0 ? plane_inlier(px[p], py[p], pz[p], ha.x, ha.y, ha.z, ha.w, tau)
-                                       : cyl_inlier(px[p], py[p], pz[p], ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, bd.x, bd.y);
-            c += (uint32_t)__popcll(__ballot(in));
+    float h0 = __builtin_nanf(""), h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, lo2 = 0, hi2 = 0;
+    if (lane < K) {
+        const uint32_t h = sel[lane];
+        const float4 a = *reinterpret_cast<const float4 *>(hyp8 + 8 * (size_t)h);
+        h0 = a.x; h1 = a.y; h2 = a.z; h3 = a.w;
+        if (MODEL == 1) {
+            const float4 b = *reinterpret_cast<const float4 *>(hyp8 + 8 * (size_t)h + 4);
+            const float2 bd = band[h];
+            h4 = b.x; h5 = b.y; lo2 = bd.x; hi2 = bd.y;
         }
-        if (lane_id() == 0 && c) atomicAdd(&lcnt[k], c);
     }
+    wave_lds_fence();  // every wave reads only the points it staged itself
+    float c = 0.f;
+    for (uint32_t gi = 0; gi < groups; ++gi) {
+        const float4 X = lp[wave][gi][0], Y = lp[wave][gi][1], Z = lp[wave][gi][2];  // broadcast reads: 4 points
+        const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (MODEL == 0) c += plane_inlier(xs[q], ys[q], zs[q], h0, h1, h2, h3, tau) ? 1.0f : 0.0f;
+            else c += cyl_inlier(xs[q], ys[q], zs[q], h0, h1, h2, h3, h4, h5, lo2, hi2) ? 1.0f : 0.0f;
+        }
+    }
+    red[wave][lane] = c;
     __syncthreads();
-    if (threadIdx.x < K) {
-        const uint32_t c = lcnt[threadIdx.x];
-        if (c) atomicAdd(&counts_k[threadIdx.x], (int32_t)c);
+    if (wave == 0 && lane < K) {
+        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];  // exact: integers <= 1024
+        if (t > 0.f) atomicAdd(&counts_k[lane], (int32_t)t);
     }
 }
 
@@ -359,26 +370,33 @@ __global__ __launch_bounds__(64) void k_best_of_selected(const int32_t *__restri
     best[0] = bi; best[1] = bc;
 }
 
+// init != 0: this is the first model of the frame -- every point is eligible and labels are WRITTEN for all
+// points (no memset of the label array is needed); otherwise only points with labels == want are touched.
 template <int MODEL>
 __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, uint8_t *__restrict__ labels,
                                                uint32_t want, uint32_t label, const uint32_t *__restrict__ n_ptr,
                                                uint32_t n_host, const float *__restrict__ hyp8,
                                                const float2 *__restrict__ band, const uint32_t *__restrict__ best,
-                                               float tau)
+                                               float tau, int init)
 {
     const uint32_t n = n_ptr ? *n_ptr : n_host;
     const uint32_t h = best[0];
-    if (h == 0xFFFFFFFFu) return;
+    if (h == 0xFFFFFFFFu) {
+        if (init)
+            for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) labels[i] = 0;
+        return;
+    }
     const float *hy = hyp8 + 8 * (size_t)h;
     const float a = hy[0], b = hy[1], c = hy[2], d = hy[3], e = hy[4], f = hy[5];
     float lo2 = 0, hi2 = 0;
     if (MODEL == 1) { const float2 bd = band[h]; lo2 = bd.x; hi2 = bd.y; }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (labels[i] != want) continue;
+        if (!init && labels[i] != want) continue;
         const float4 p = pts[i];
         const bool in = MODEL == 0 ? plane_inlier(p.x, p.y, p.z, a, b, c, d, tau)
                                    : cyl_inlier(p.x, p.y, p.z, a, b, c, d, e, f, lo2, hi2);
-        if (in) labels[i] = (uint8_t)label;
+        if (init) labels[i] = in ? (uint8_t)label : (uint8_t)0;
+        else if (in) labels[i] = (uint8_t)label;
     }
 }
 
@@ -534,29 +552,28 @@ void launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels
     const dim3 grid(nb, (H + kScHC - 1) / kScHC);
     uint32_t *sel = scratch;
     int32_t *counts_k = (int32_t *)(scratch + kPreKeep);
-    hipMemsetAsync(counts, 0, sizeof(int32_t) * H, s);
-    hipMemsetAsync(counts_k, 0, sizeof(int32_t) * kPreKeep, s);
+    hipMemsetAsync(counts, 0, sizeof(int32_t) * H, s);  // counts_k is zeroed by k_select_topk
     if (model == 1) hipLaunchKernelGGL(k_cyl_bands, dim3((H + 255) / 256), dim3(256), 0, s, hyp8, H, tau, band);
     const uint32_t K = kPreKeep;
     const uint32_t nbf = (n_cap + 1023) / 1024 ? (n_cap + 1023) / 1024 : 1;
     if (model == 0) {
         hipLaunchKernelGGL(k_score<0>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
                            (const float2 *)band, H, (float)tau, (uint32_t)kPreStride, counts);
-        hipLaunchKernelGGL(k_select_topk, dim3((H + 63) / 64), dim3(64), sizeof(int32_t) * H, s, (const int32_t *)counts, H, K, sel);
-        hipLaunchKernelGGL(k_score_few<0>, dim3(nbf), dim3(256), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
+        hipLaunchKernelGGL(k_select_topk, dim3((H + 15) / 16), dim3(256), sizeof(int32_t) * H, s, (const int32_t *)counts, H, K, sel, counts_k);
+        hipLaunchKernelGGL(k_score_sel<0>, dim3(nbf), dim3(256), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
                            (const float2 *)band, (const uint32_t *)sel, K, (float)tau, counts_k);
     } else {
         hipLaunchKernelGGL(k_score<1>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
                            (const float2 *)band, H, (float)tau, (uint32_t)kPreStride, counts);
-        hipLaunchKernelGGL(k_select_topk, dim3((H + 63) / 64), dim3(64), sizeof(int32_t) * H, s, (const int32_t *)counts, H, K, sel);
-        hipLaunchKernelGGL(k_score_few<1>, dim3(nbf), dim3(256), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
+        hipLaunchKernelGGL(k_select_topk, dim3((H + 15) / 16), dim3(256), sizeof(int32_t) * H, s, (const int32_t *)counts, H, K, sel, counts_k);
+        hipLaunchKernelGGL(k_score_sel<1>, dim3(nbf), dim3(256), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
                            (const float2 *)band, (const uint32_t *)sel, K, (float)tau, counts_k);
     }
     hipLaunchKernelGGL(k_best_of_selected, dim3(1), dim3(64), 0, s, (const int32_t *)counts_k, (const uint32_t *)sel, K, best);
 }
 
 void launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, uint32_t label, const uint32_t *n_ptr,
-                  uint32_t n_cap, const float *hyp8, const float2 *band, const uint32_t *best, double tau,
+                  uint32_t n_cap, const float *hyp8, const float2 *band, const uint32_t *best, double tau, int init,
                   hipStream_t s)
 {
     uint32_t nb = (n_cap + 255) / 256;
@@ -564,10 +581,10 @@ void launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, 
     if (nb == 0) nb = 1;
     if (model == 0)
         hipLaunchKernelGGL(k_label<0>, dim3(nb), dim3(256), 0, s, pts, labels, want, label, n_ptr, n_cap, hyp8, band,
-                           best, (float)tau);
+                           best, (float)tau, init);
     else
         hipLaunchKernelGGL(k_label<1>, dim3(nb), dim3(256), 0, s, pts, labels, want, label, n_ptr, n_cap, hyp8, band,
-                           best, (float)tau);
+                           best, (float)tau, init);
 }
 
 void launch_segment_moments(const float4 *pts, const float4 *nrm, const uint8_t *labels, uint32_t label,
