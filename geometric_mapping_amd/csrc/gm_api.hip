@@ -54,6 +54,10 @@ void free_slot_buffers(Slot &sl)
 
 // search grid over the crop box: cell edge >= 1.001 r in y and z (<= 1024 cells per axis), x binned
 // `fine` times finer (a power of two chosen so that the cell key still fits 31 bits)
+// The neighbour predicate of k_normals needs one ulp of r^2, scaled by a power of two <= 2^126, to reach 1: true for
+// every radius >= 1e-15 m (and the radius 0, "no neighbours", is handled exactly as well).
+static bool radius_ok(double r) { return std::isfinite(r) && (r == 0.0 || (r >= 1e-15 && r <= 1e15)); }
+
 GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, float ez, double radius)
 {
     GridParams g;
@@ -72,6 +76,13 @@ GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, flo
     g.nx = dim(ex, g.inv_hx, 1024 * fine);
     g.xreach = fine + 1;
     g.r2 = (float)(radius * radius);  // KdTreeFLANN::radiusSearch: static_cast<float>(radius*radius)
+    {
+        int e = 0;
+        (void)frexpf(g.r2 > 0.f ? g.r2 : 1.f, &e);  // r2 = m * 2^e, m in [0.5, 1)
+        int k = 100 - e;
+        k = k > 126 ? 126 : (k < -100 ? -100 : k);  // never clamps for the radii radius_ok() admits
+        g.r2_scale = ldexpf(1.0f, k);
+    }
     return g;
 }
 
@@ -398,26 +409,29 @@ gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap)
     bool first = true;
     if (do_plane) {
         uint8_t *lab = first ? nullptr : sl.labels;
-        launch_plane_hypotheses(sl.valid4, lab, 0, n_ptr, n_cap, cf.ransac_seed, H, sl.hyp_plane, s);
-        launch_score_preemptive(0, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_plane, sl.band, H, cf.ransac_threshold,
-                                sl.score_partial, sl.cnt_plane, sl.best_plane, s);
+        launch_plane_hypotheses(sl.valid4, lab, 0, n_ptr, n_cap, cf.ransac_seed, H, sl.hyp_plane, sl.cnt_plane, s);
+        const bool from_sel = launch_score_preemptive(0, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_plane, sl.band, H,
+                                                      cf.ransac_threshold, sl.score_partial, sl.cnt_plane, sl.best_plane,
+                                                      true, s);
         launch_label(0, sl.valid4, sl.labels, 0, 1, n_ptr, n_cap, sl.hyp_plane, sl.band, sl.best_plane,
-                     cf.ransac_threshold, first ? 1 : 0, s);
-        launch_segment_moments(sl.valid4, sl.vnorm4, sl.labels, 1, n_ptr, n_cap, sl.mom_partial, sl.mom_plane, s);
+                     cf.ransac_threshold, first ? 1 : 0, from_sel ? sl.score_partial : nullptr, s);
         first = false;
     }
     if (do_cyl) {
         uint8_t *lab = first ? nullptr : sl.labels;
-        launch_cylinder_hypotheses(sl.valid4, sl.vnorm4, lab, 0, n_ptr, n_cap, cf.ransac_seed + 1, H, sl.hyp_cyl, s);
-        launch_score_preemptive(1, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_cyl, sl.band, H, cf.ransac_threshold,
-                                sl.score_partial, sl.cnt_cyl, sl.best_cyl, s);
+        launch_cylinder_hypotheses(sl.valid4, sl.vnorm4, lab, 0, n_ptr, n_cap, cf.ransac_seed + 1, H, sl.hyp_cyl,
+                                   sl.cnt_cyl, sl.band, cf.ransac_threshold, s);
+        const bool from_sel = launch_score_preemptive(1, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_cyl, sl.band, H,
+                                                      cf.ransac_threshold, sl.score_partial, sl.cnt_cyl, sl.best_cyl,
+                                                      true, s);
         launch_label(1, sl.valid4, sl.labels, 0, 2, n_ptr, n_cap, sl.hyp_cyl, sl.band, sl.best_cyl,
-                     cf.ransac_threshold, first ? 1 : 0, s);
-        launch_segment_moments(sl.valid4, sl.vnorm4, sl.labels, 2, n_ptr, n_cap, sl.mom_partial, sl.mom_cyl, s);
+                     cf.ransac_threshold, first ? 1 : 0, from_sel ? sl.score_partial : nullptr, s);
         first = false;
     }
+    // one pass over the labelled cloud for the moments of both segments; its partials are reduced by the finalizer
+    const uint32_t mom_rows = launch_frame_moments(sl.valid4, sl.vnorm4, sl.labels, n_ptr, n_cap, sl.mom_partial, s);
     launch_ext_finalize(sl.hyp_plane, do_plane ? sl.best_plane : nullptr, sl.hyp_cyl, do_cyl ? sl.best_cyl : nullptr,
-                        sl.mom_plane, sl.mom_cyl, &sl.d_out->ext, s);
+                        sl.mom_plane, sl.mom_cyl, &sl.d_out->ext, sl.mom_partial, mom_rows, s);
     return GM_OK;
 }
 
@@ -477,7 +491,7 @@ gm_status gm_create(const gm_config *cfg, gm_ctx **out)
     *out = nullptr;
     if (cfg->struct_size != sizeof(gm_config)) return fail(nullptr, GM_ERR_INVALID_ARG, "gm_config.struct_size mismatch");
     if (!(cfg->weightingFactor != 0.0) || !std::isfinite(cfg->boxFilterBound) || !(cfg->boxFilterBound >= 0.0) ||
-        !(cfg->voxelGridLeafSize > 0.0) || !(cfg->neighborRadius >= 0.0))
+        !(cfg->voxelGridLeafSize > 0.0) || !radius_ok(cfg->neighborRadius))
         return fail(nullptr, GM_ERR_INVALID_ARG, "gm_config: bad numeric parameter");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -673,7 +687,7 @@ gm_status gm_get_normals_stage(gm_ctx *ctx, const float *xyz, uint32_t n, double
     gm_status st = begin_stage(ctx, slp);
     if (st != GM_OK) return st;
     if (n && !xyz) return fail(ctx, GM_ERR_INVALID_ARG, "xyz is NULL");
-    if (!(radius >= 0.0) || !std::isfinite(radius)) return fail(ctx, GM_ERR_INVALID_ARG, "radius must be finite and >= 0");
+    if (!radius_ok(radius)) return fail(ctx, GM_ERR_INVALID_ARG, "radius must be 0 or within [1e-15, 1e15]");
     Slot &sl = *slp;
     const size_t raw_bytes = (size_t)n * 12;
     st = ensure_capacity(ctx, sl, n, raw_bytes, true);

@@ -45,6 +45,8 @@ struct GridParams {
     int32_t nx, ny, nz; // cells per axis (nx counts the fine x cells)
     int32_t xreach;     // fine x cells that cover the radius (fine + 1)
     float r2;           // (float)(radius*radius): KdTreeFLANN::radiusSearch's cast
+    float r2_scale;     // power of two s with r2 * s ~ 2^100: k_normals evaluates d2 < r2 as clamp01(fma(d2, -s, r2 * s)),
+                        // exact because one ulp of a d2 next to r2, times s, is >= 2^76
 };
 
 // Dense voxel table (fast path of the VoxelGrid stage): when the crop box bounds

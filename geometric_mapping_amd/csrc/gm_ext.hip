@@ -110,7 +110,8 @@ gm_status gm_plane_hypotheses(gm_ctx *ctx, const float *xyz, uint32_t n, const u
     if (st != GM_OK) return st;
     st = upload_labels(ctx, sl, labels, n);
     if (st != GM_OK) return st;
-    launch_plane_hypotheses(sl.valid4, labels ? sl.labels : nullptr, want, nullptr, n, seed, H, sl.hyp_plane, sl.stream);
+    launch_plane_hypotheses(sl.valid4, labels ? sl.labels : nullptr, want, nullptr, n, seed, H, sl.hyp_plane, nullptr,
+                            sl.stream);
     if ((size_t)H * 32 > sl.raw_cap) {
         st = gm_ensure_capacity(ctx, sl, n, (size_t)H * 32, true);
         if (st != GM_OK) return st;
@@ -139,7 +140,7 @@ gm_status gm_cylinder_hypotheses(gm_ctx *ctx, const float *xyz, const float *nxy
     st = upload_labels(ctx, sl, labels, n);
     if (st != GM_OK) return st;
     launch_cylinder_hypotheses(sl.valid4, sl.vnorm4, labels ? sl.labels : nullptr, want, nullptr, n, seed, H, sl.hyp_cyl,
-                               sl.stream);
+                               nullptr, nullptr, 0.0, sl.stream);
     if ((size_t)H * 32 > sl.raw_cap) {
         st = gm_ensure_capacity(ctx, sl, n, (size_t)H * 32, true);
         if (st != GM_OK) return st;

@@ -120,24 +120,28 @@ constexpr uint32_t kVoxDenseMaxCells = 1u << 18;
 constexpr uint32_t kMaxHypotheses = 8192;
 uint32_t score_blocks(uint32_t n_cap);
 void launch_plane_hypotheses(const float4 *pts, const uint8_t *labels, uint32_t want, const uint32_t *n_ptr,
-                             uint32_t n_host, uint64_t seed, uint32_t H, float *hyp8, hipStream_t s);
+                             uint32_t n_host, uint64_t seed, uint32_t H, float *hyp8, int32_t *zero_counts,
+                             hipStream_t s);
 void launch_cylinder_hypotheses(const float4 *pts, const float4 *nrm, const uint8_t *labels, uint32_t want,
                                 const uint32_t *n_ptr, uint32_t n_host, uint64_t seed, uint32_t H, float *hyp8,
-                                hipStream_t s);
+                                int32_t *zero_counts, float2 *band, double tau, hipStream_t s);
 void launch_score(int model, const float4 *pts, const uint8_t *labels, uint32_t want, const uint32_t *n_ptr,
                   uint32_t n_cap, const float *hyp8, float2 *band, uint32_t H, double tau, uint32_t *partial,
                   int32_t *counts, uint32_t *best, hipStream_t s);
-void launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels, uint32_t want,
+bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels, uint32_t want,
                              const uint32_t *n_ptr, uint32_t n_cap, const float *hyp8, float2 *band, uint32_t H,
-                             double tau, uint32_t *scratch, int32_t *counts, uint32_t *best, hipStream_t s);
+                             double tau, uint32_t *scratch, int32_t *counts, uint32_t *best, bool prepared,
+                             hipStream_t s);
 void launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, uint32_t label, const uint32_t *n_ptr,
-                  uint32_t n_cap, const float *hyp8, const float2 *band, const uint32_t *best, double tau, int init,
-                  hipStream_t s);
+                  uint32_t n_cap, const float *hyp8, const float2 *band, uint32_t *best, double tau, int init,
+                  const uint32_t *sel_scratch, hipStream_t s);
 void launch_segment_moments(const float4 *pts, const float4 *nrm, const uint8_t *labels, uint32_t label,
                             const uint32_t *n_ptr, uint32_t n_cap, double *partial, double *mom16, hipStream_t s);
+uint32_t launch_frame_moments(const float4 *pts, const float4 *nrm, const uint8_t *labels, const uint32_t *n_ptr,
+                              uint32_t n_cap, double *partial32, hipStream_t s);
 void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, const float *hyp_cyl,
-                         const uint32_t *best_cyl, const double *mom_plane, const double *mom_cyl, FrameExt *ext,
-                         hipStream_t s);
+                         const uint32_t *best_cyl, double *mom_plane, double *mom_cyl, FrameExt *ext,
+                         const double *partial32, uint32_t mom_rows, hipStream_t s);
 // k_nearest.hip
 void launch_nearest(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, const float4 *queries,
                     const uint32_t *nq_ptr, uint32_t nq_cap, unsigned long long *best, int32_t *idx, hipStream_t s);

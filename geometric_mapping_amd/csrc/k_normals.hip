@@ -49,9 +49,10 @@ __device__ __forceinline__ v2f pk_add_rn(v2f a, v2f b)
     return r;
 }
 
-// 1.0 where d2 < r2 (strictly), else 0.0, for both halves in ONE VALU op: clamp01(fma(d2, -2^100, r2 * 2^100)).
-// The fma rounds 2^100 * (r2 - d2) once, so its sign is exact and it is zero only when d2 == r2; any positive
-// value is >= 2^100 * ulp >> 1 and clamps to 1, overflow to -inf clamps to 0.  (v_cmp + v_cndmask per half costs
+// 1.0 where d2 < r2 (strictly), else 0.0, for both halves in ONE VALU op: clamp01(fma(d2, -s, r2 * s)) with
+// s = GridParams::r2_scale, a power of two with r2 * s ~ 2^100.  The fma rounds s * (r2 - d2) once, so its sign is
+// exact and it is zero only when d2 == r2; any positive value is >= s * ulp(r2) / 2 >= 2^75 and clamps to 1, negative
+// values and the overflow to -inf of far padding clamp to 0.  (v_cmp + v_cndmask per half costs
 // four issue slots and a VALU->SGPR hazard.)
 __device__ __forceinline__ v2f pk_within(v2f d2, v2f neg_big, v2f r2_big)
 {
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
 #pragma unroll
         for (int k = 0; k < 10; ++k) T[k * kWave] = 0.0;
         const v2f qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
-        const float big = 0x1p100f;
+        const float big = g.r2_scale;  // power of two chosen by the host so that r2 * big ~ 2^100
         const v2f neg_big = {-big, -big}, r2_big = {g.r2 * big, g.r2 * big};  // exact scalings
         float *wx = &win[w][0][0], *wy = &win[w][1][0], *wz = &win[w][2][0];
         v2f sn = {0, 0}, sx = {0, 0}, sy = {0, 0}, sz = {0, 0}, sxx = {0, 0}, sxy = {0, 0}, sxz = {0, 0},

@@ -57,14 +57,25 @@ __device__ inline void store_nan(float *o, int k)
     for (int i = 0; i < k; ++i) o[i] = __builtin_nanf("");
 }
 
+// inlier band of a cylinder hypothesis: (r-tau)^2 < dist_axis^2 < (r+tau)^2, both ends in fp32
+__host__ __device__ inline void cyl_band(float r, double tau, float &lo2, float &hi2)
+{
+    const double lo = (double)r - tau, hi = (double)r + tau;
+    lo2 = lo > 0 ? (float)(lo * lo) : -1.0f;
+    hi2 = (float)(hi * hi);
+}
+
 // hyp8 rows: plane a,b,c,d,-,-,-,-   cylinder px,py,pz,dx,dy,dz,r,-
+// (zero_counts != nullptr: the kernel also clears the score counter of its hypothesis, so the frame pipeline needs no memset)
 __global__ __launch_bounds__(256) void k_plane_hypotheses(const float4 *__restrict__ pts,
                                                           const uint8_t *__restrict__ labels, uint32_t want,
                                                           const uint32_t *__restrict__ n_ptr, uint32_t n_host,
-                                                          uint64_t seed, uint32_t H, float *__restrict__ hyp8)
+                                                          uint64_t seed, uint32_t H, float *__restrict__ hyp8,
+                                                          int32_t *__restrict__ zero_counts)
 {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= H) return;
+    if (zero_counts) zero_counts[h] = 0;
     const uint32_t n = n_ptr ? *n_ptr : n_host;
     float *o = hyp8 + 8 * (size_t)h;
     for (int k = 4; k < 8; ++k) o[k] = 0.f;
@@ -86,16 +97,10 @@ __global__ __launch_bounds__(256) void k_plane_hypotheses(const float4 *__restri
     o[0] = (float)nx; o[1] = (float)ny; o[2] = (float)nz; o[3] = (float)d;
 }
 
-__global__ __launch_bounds__(256) void k_cylinder_hypotheses(const float4 *__restrict__ pts,
-                                                             const float4 *__restrict__ nrm,
-                                                             const uint8_t *__restrict__ labels, uint32_t want,
-                                                             const uint32_t *__restrict__ n_ptr, uint32_t n_host,
-                                                             uint64_t seed, uint32_t H, float *__restrict__ hyp8)
+__device__ inline void cylinder_hypothesis(const float4 *__restrict__ pts, const float4 *__restrict__ nrm,
+                                           const uint8_t *__restrict__ labels, uint32_t want, uint32_t n, uint64_t seed,
+                                           uint32_t h, float *o /* [8] */)
 {
-    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= H) return;
-    const uint32_t n = n_ptr ? *n_ptr : n_host;
-    float *o = hyp8 + 8 * (size_t)h;
     o[7] = 0.f;
     if (n < 2) { store_nan(o, 7); return; }
     uint32_t t = 0;
@@ -132,12 +137,28 @@ __global__ __launch_bounds__(256) void k_cylinder_hypotheses(const float4 *__res
     o[6] = (float)r;
 }
 
-// inlier band of a cylinder hypothesis: (r-tau)^2 < dist_axis^2 < (r+tau)^2, both ends in fp32
-__host__ __device__ inline void cyl_band(float r, double tau, float &lo2, float &hi2)
+__global__ __launch_bounds__(256) void k_cylinder_hypotheses(const float4 *__restrict__ pts,
+                                                             const float4 *__restrict__ nrm,
+                                                             const uint8_t *__restrict__ labels, uint32_t want,
+                                                             const uint32_t *__restrict__ n_ptr, uint32_t n_host,
+                                                             uint64_t seed, uint32_t H, float *__restrict__ hyp8,
+                                                             int32_t *__restrict__ zero_counts, float2 *__restrict__ band,
+                                                             double tau)
 {
-    const double lo = (double)r - tau, hi = (double)r + tau;
-    lo2 = lo > 0 ? (float)(lo * lo) : -1.0f;
-    hi2 = (float)(hi * hi);
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    float o[8];
+    cylinder_hypothesis(pts, nrm, labels, want, n, seed, h, o);
+    float4 *dst = reinterpret_cast<float4 *>(hyp8 + 8 * (size_t)h);
+    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    if (zero_counts) zero_counts[h] = 0;
+    if (band) {  // the scorer's inlier band of this hypothesis (k_cyl_bands for caller-supplied hypotheses)
+        float lo2, hi2;
+        cyl_band(o[6], tau, lo2, hi2);
+        band[h] = make_float2(lo2, hi2);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_cyl_bands(const float *__restrict__ hyp8, uint32_t H, double tau,
@@ -356,31 +377,39 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
     }
 }
 
-// winner among the re-scored hypotheses: largest full count, lowest hypothesis index on ties
-__global__ __launch_bounds__(64) void k_best_of_selected(const int32_t *__restrict__ counts_k,
-                                                         const uint32_t *__restrict__ sel, uint32_t K,
-                                                         uint32_t *__restrict__ best)
-{
-    if (threadIdx.x != 0) return;
-    uint32_t bi = 0xFFFFFFFFu, bc = 0;
-    for (uint32_t k = 0; k < K; ++k) {
-        const uint32_t c = (uint32_t)counts_k[k], h = sel[k];
-        if (bi == 0xFFFFFFFFu || c > bc || (c == bc && h < bi)) { bc = c; bi = h; }
-    }
-    best[0] = bi; best[1] = bc;
-}
 
 // init != 0: this is the first model of the frame -- every point is eligible and labels are WRITTEN for all
 // points (no memset of the label array is needed); otherwise only points with labels == want are touched.
+// counts_k != nullptr: the winner is taken from the K re-scored hypotheses (largest count, lowest hypothesis index
+// on ties) by every block for itself, and block 0 publishes it in best[0..1] (k_best_of_selected folded in).
 template <int MODEL>
 __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, uint8_t *__restrict__ labels,
                                                uint32_t want, uint32_t label, const uint32_t *__restrict__ n_ptr,
                                                uint32_t n_host, const float *__restrict__ hyp8,
-                                               const float2 *__restrict__ band, const uint32_t *__restrict__ best,
-                                               float tau, int init)
+                                               const float2 *__restrict__ band, uint32_t *__restrict__ best,
+                                               float tau, int init, const int32_t *__restrict__ counts_k,
+                                               const uint32_t *__restrict__ sel, uint32_t K)
 {
     const uint32_t n = n_ptr ? *n_ptr : n_host;
-    const uint32_t h = best[0];
+    uint32_t h;
+    if (counts_k) {
+        __shared__ uint32_t win[2];
+        if (threadIdx.x < kWave) {
+            uint32_t c = 0, hi = 0xFFFFFFFFu;
+            if (threadIdx.x < K) { c = (uint32_t)counts_k[threadIdx.x]; hi = sel[threadIdx.x]; }
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const uint32_t oc = __shfl_xor(c, o, kWave), oh = __shfl_xor(hi, o, kWave);
+                if (oh != 0xFFFFFFFFu && (hi == 0xFFFFFFFFu || oc > c || (oc == c && oh < hi))) { c = oc; hi = oh; }
+            }
+            if (threadIdx.x == 0) { win[0] = hi; win[1] = c; }
+        }
+        __syncthreads();
+        h = win[0];
+        if (blockIdx.x == 0 && threadIdx.x == 0) { best[0] = win[0]; best[1] = win[1]; }
+    } else {
+        h = best[0];
+    }
     if (h == 0xFFFFFFFFu) {
         if (init)
             for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) labels[i] = 0;
@@ -458,11 +487,80 @@ __global__ __launch_bounds__(256) void k_moments_finalize(const double *__restri
 }
 
 // refits + copy of the winning hypotheses into the frame record
-__global__ void k_ext_finalize(const float *__restrict__ hyp_plane, const uint32_t *__restrict__ best_plane,
-                               const float *__restrict__ hyp_cyl, const uint32_t *__restrict__ best_cyl,
-                               const double *__restrict__ mom_plane, const double *__restrict__ mom_cyl,
-                               FrameExt *__restrict__ ext)
+// Frame pipeline: the moments of BOTH segments (label 1 = plane inliers: point moments; label 2 = cylinder inliers:
+// point and normal moments) in one pass over the labelled cloud.  partial rows: [0..15] plane, [16..31] cylinder.
+__global__ __launch_bounds__(256) void k_frame_moments(const float4 *__restrict__ pts, const float4 *__restrict__ nrm,
+                                                       const uint8_t *__restrict__ labels,
+                                                       const uint32_t *__restrict__ n_ptr, uint32_t n_host,
+                                                       double *__restrict__ partial /* [gridDim.x][32] */)
 {
+    __shared__ double red[256 / kWave][32];
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    double a[10], b[16];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) a[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) b[k] = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t l = labels[i];
+        if (l != 1u && l != 2u) continue;
+        const float4 p = pts[i];
+        const double x = p.x, y = p.y, z = p.z;
+        if (l == 1u) {
+            a[0] += 1.0; a[1] += x; a[2] += y; a[3] += z;
+            a[4] += x * x; a[5] += x * y; a[6] += x * z; a[7] += y * y; a[8] += y * z; a[9] += z * z;
+        } else {
+            const float4 q = nrm[i];
+            const double u = q.x, v = q.y, w = q.z;
+            b[0] += 1.0; b[1] += x; b[2] += y; b[3] += z;
+            b[4] += x * x; b[5] += x * y; b[6] += x * z; b[7] += y * y; b[8] += y * z; b[9] += z * z;
+            b[10] += u * u; b[11] += u * v; b[12] += u * w; b[13] += v * v; b[14] += v * w; b[15] += w * w;
+        }
+    }
+    const int w = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double ra = k < 10 ? wave_sum(a[k]) : 0.0, rb = wave_sum(b[k]);
+        if (lane_id() == 0) { red[w][k] = ra; red[w][16 + k] = rb; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double r = 0;
+#pragma unroll
+        for (int j = 0; j < 256 / kWave; ++j) r += red[j][threadIdx.x];
+        partial[(size_t)blockIdx.x * 32 + threadIdx.x] = r;
+    }
+}
+
+// mom_rows > 0: first reduce the k_frame_moments partials (fixed order) into mom_plane / mom_cyl, then finalize.
+__global__ __launch_bounds__(256) void k_ext_finalize(const float *__restrict__ hyp_plane, const uint32_t *__restrict__ best_plane,
+                               const float *__restrict__ hyp_cyl, const uint32_t *__restrict__ best_cyl,
+                               double *__restrict__ mom_plane, double *__restrict__ mom_cyl,
+                               FrameExt *__restrict__ ext, const double *__restrict__ partial, uint32_t mom_rows)
+{
+    if (mom_rows) {
+        __shared__ double red[8][32];
+        const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
+        double r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // four independent chains: the loads of a trip are all in flight together
+        uint32_t b = part;
+        for (; b + 24 < mom_rows; b += 32) {
+            r0 += partial[(size_t)b * 32 + col];
+            r1 += partial[(size_t)(b + 8) * 32 + col];
+            r2 += partial[(size_t)(b + 16) * 32 + col];
+            r3 += partial[(size_t)(b + 24) * 32 + col];
+        }
+        for (; b < mom_rows; b += 8) r0 += partial[(size_t)b * 32 + col];
+        red[part][col] = (r0 + r1) + (r2 + r3);
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            double t = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+            if (threadIdx.x < 16) mom_plane[threadIdx.x] = t; else mom_cyl[threadIdx.x - 16] = t;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     FrameExt e;
     for (int k = 0; k < 4; ++k) { e.plane[k] = __builtin_nanf(""); e.plane_refit[k] = __builtin_nan(""); }
@@ -503,18 +601,19 @@ __global__ void k_ext_finalize(const float *__restrict__ hyp_plane, const uint32
 uint32_t score_blocks(uint32_t n_cap) { return (n_cap + kScTile - 1) / kScTile; }
 
 void launch_plane_hypotheses(const float4 *pts, const uint8_t *labels, uint32_t want, const uint32_t *n_ptr,
-                             uint32_t n_host, uint64_t seed, uint32_t H, float *hyp8, hipStream_t s)
+                             uint32_t n_host, uint64_t seed, uint32_t H, float *hyp8, int32_t *zero_counts,
+                             hipStream_t s)
 {
     hipLaunchKernelGGL(k_plane_hypotheses, dim3((H + 255) / 256), dim3(256), 0, s, pts, labels, want, n_ptr, n_host,
-                       seed, H, hyp8);
+                       seed, H, hyp8, zero_counts);
 }
 
 void launch_cylinder_hypotheses(const float4 *pts, const float4 *nrm, const uint8_t *labels, uint32_t want,
                                 const uint32_t *n_ptr, uint32_t n_host, uint64_t seed, uint32_t H, float *hyp8,
-                                hipStream_t s)
+                                int32_t *zero_counts, float2 *band, double tau, hipStream_t s)
 {
     hipLaunchKernelGGL(k_cylinder_hypotheses, dim3((H + 255) / 256), dim3(256), 0, s, pts, nrm, labels, want, n_ptr,
-                       n_host, seed, H, hyp8);
+                       n_host, seed, H, hyp8, zero_counts, band, tau);
 }
 
 void launch_score(int model, const float4 *pts, const uint8_t *labels, uint32_t want, const uint32_t *n_ptr,
@@ -539,21 +638,26 @@ void launch_score(int model, const float4 *pts, const uint8_t *labels, uint32_t 
 // In-frame RANSAC: preemptive scoring.  Stage 1 scores all H hypotheses on every kPreStride-th point,
 // stage 2 re-scores the kPreKeep best of them on every point; the winner is the best full count.
 // `scratch` holds sel[kPreKeep] followed by counts_k[kPreKeep].
-void launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels, uint32_t want,
+bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels, uint32_t want,
                              const uint32_t *n_ptr, uint32_t n_cap, const float *hyp8, float2 *band, uint32_t H,
-                             double tau, uint32_t *scratch, int32_t *counts, uint32_t *best, hipStream_t s)
+                             double tau, uint32_t *scratch, int32_t *counts, uint32_t *best, bool prepared,
+                             hipStream_t s)
 {
+    // prepared: the hypothesis kernel already cleared `counts` and wrote the cylinder bands.  Returns true when
+    // the winner is still to be taken from scratch (sel[K], counts_k[K]) -- the label kernel does that.
     if (H <= (uint32_t)kPreKeep) {  // nothing to pre-select
         launch_score(model, pts, labels, want, n_ptr, n_cap, hyp8, band, H, tau, nullptr, counts, best, s);
-        return;
+        return false;
     }
     const uint32_t n_sub = (n_cap + kPreStride - 1) / kPreStride;
     const uint32_t nb = score_blocks(n_sub) ? score_blocks(n_sub) : 1;
     const dim3 grid(nb, (H + kScHC - 1) / kScHC);
     uint32_t *sel = scratch;
     int32_t *counts_k = (int32_t *)(scratch + kPreKeep);
-    hipMemsetAsync(counts, 0, sizeof(int32_t) * H, s);  // counts_k is zeroed by k_select_topk
-    if (model == 1) hipLaunchKernelGGL(k_cyl_bands, dim3((H + 255) / 256), dim3(256), 0, s, hyp8, H, tau, band);
+    if (!prepared) {
+        hipMemsetAsync(counts, 0, sizeof(int32_t) * H, s);  // (counts_k is zeroed by k_select_topk)
+        if (model == 1) hipLaunchKernelGGL(k_cyl_bands, dim3((H + 255) / 256), dim3(256), 0, s, hyp8, H, tau, band);
+    }
     const uint32_t K = kPreKeep;
     const uint32_t nbf = (n_cap + 1023) / 1024 ? (n_cap + 1023) / 1024 : 1;
     if (model == 0) {
@@ -569,40 +673,54 @@ void launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels
         hipLaunchKernelGGL(k_score_sel<1>, dim3(nbf), dim3(256), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
                            (const float2 *)band, (const uint32_t *)sel, K, (float)tau, counts_k);
     }
-    hipLaunchKernelGGL(k_best_of_selected, dim3(1), dim3(64), 0, s, (const int32_t *)counts_k, (const uint32_t *)sel, K, best);
+    return true;
 }
 
 void launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, uint32_t label, const uint32_t *n_ptr,
-                  uint32_t n_cap, const float *hyp8, const float2 *band, const uint32_t *best, double tau, int init,
-                  hipStream_t s)
+                  uint32_t n_cap, const float *hyp8, const float2 *band, uint32_t *best, double tau, int init,
+                  const uint32_t *sel_scratch, hipStream_t s)
 {
+    // sel_scratch != nullptr: winner = best of the kPreKeep re-scored hypotheses in (sel[K], counts_k[K])
+    const uint32_t *sel = sel_scratch;
+    const int32_t *counts_k = sel_scratch ? (const int32_t *)(sel_scratch + kPreKeep) : nullptr;
+    const uint32_t K = kPreKeep;
     uint32_t nb = (n_cap + 255) / 256;
     if (nb > 2048) nb = 2048;
     if (nb == 0) nb = 1;
     if (model == 0)
         hipLaunchKernelGGL(k_label<0>, dim3(nb), dim3(256), 0, s, pts, labels, want, label, n_ptr, n_cap, hyp8, band,
-                           best, (float)tau, init);
+                           best, (float)tau, init, counts_k, sel, K);
     else
         hipLaunchKernelGGL(k_label<1>, dim3(nb), dim3(256), 0, s, pts, labels, want, label, n_ptr, n_cap, hyp8, band,
-                           best, (float)tau, init);
+                           best, (float)tau, init, counts_k, sel, K);
 }
 
 void launch_segment_moments(const float4 *pts, const float4 *nrm, const uint8_t *labels, uint32_t label,
                             const uint32_t *n_ptr, uint32_t n_cap, double *partial, double *mom16, hipStream_t s)
 {
     uint32_t nb = (n_cap + 255) / 256;
-    if (nb > 256u) nb = 256u;
+    if (nb > (uint32_t)kScatterBlocks) nb = kScatterBlocks;  // 4 blocks per CU: enough loads in flight to stream
     if (nb == 0) nb = 1;
     hipLaunchKernelGGL(k_segment_moments, dim3(nb), dim3(256), 0, s, pts, nrm, labels, label, n_ptr, n_cap, partial);
     hipLaunchKernelGGL(k_moments_finalize, dim3(1), dim3(256), 0, s, (const double *)partial, nb, mom16);
 }
 
-void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, const float *hyp_cyl,
-                         const uint32_t *best_cyl, const double *mom_plane, const double *mom_cyl, FrameExt *ext,
-                         hipStream_t s)
+uint32_t launch_frame_moments(const float4 *pts, const float4 *nrm, const uint8_t *labels, const uint32_t *n_ptr,
+                              uint32_t n_cap, double *partial32, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_ext_finalize, dim3(1), dim3(64), 0, s, hyp_plane, best_plane, hyp_cyl, best_cyl, mom_plane,
-                       mom_cyl, ext);
+    uint32_t nb = (n_cap + 255) / 256;
+    if (nb > (uint32_t)kScatterBlocks / 2) nb = kScatterBlocks / 2;  // partial32 = [kScatterBlocks * 16] doubles = 512 rows
+    if (nb == 0) nb = 1;
+    hipLaunchKernelGGL(k_frame_moments, dim3(nb), dim3(256), 0, s, pts, nrm, labels, n_ptr, n_cap, partial32);
+    return nb;
+}
+
+void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, const float *hyp_cyl,
+                         const uint32_t *best_cyl, double *mom_plane, double *mom_cyl, FrameExt *ext,
+                         const double *partial32, uint32_t mom_rows, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ext_finalize, dim3(1), dim3(256), 0, s, hyp_plane, best_plane, hyp_cyl, best_cyl, mom_plane,
+                       mom_cyl, ext, partial32, mom_rows);
 }
 
 }  // namespace gm

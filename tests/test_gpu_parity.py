@@ -115,6 +115,30 @@ def test_get_normals_radius_strict(ctx):
     assert ctx.neighbor_counts().tolist() == [4, 2, 2, 2]
 
 
+def test_get_normals_radius_extremes_vs_oracle(ctx, oc, gm):
+    """The neighbour predicate d2 < (float)(r*r) must stay exact at every radius scale (the kernel evaluates it as a
+    clamped fma with a radius-dependent power-of-two scale): tiny radii with coincident / nearly coincident points,
+    huge radii (every point a neighbour), and points sitting exactly ON the radius."""
+    rng = np.random.default_rng(11)
+    base = rng.uniform(-1.0, 1.0, size=(300, 3)).astype(np.float32)
+    dup = np.repeat(base[:40], 3, axis=0)                                  # coincident triples
+    near = (base[:60] + np.float32(1e-6) * rng.standard_normal((60, 3))).astype(np.float32)
+    cloud = np.vstack([base, dup, near]).astype(np.float32)
+    for radius in (1e-12, 1e-7, 3e-6, 0.05, 0.7, 50.0, 1e6, 1e12):
+        ctx.getNormals(radius, cloud)
+        _, o_cnt = oc.normals(cloud, radius, oc.F64)
+        assert np.array_equal(ctx.neighbor_counts(), o_cnt), radius
+    # exact ties: lattice points at distance exactly r (d2 == r2 in fp32) are NOT neighbours, at several scales
+    for scale in (2.0 ** -20, 2.0 ** -3, 1.0, 2.0 ** 10):
+        pts = (np.array([[0, 0, 0], [3, 4, 0], [0, 3, 4], [4, 0, 3], [1, 1, 1]], dtype=np.float64) * scale).astype(np.float32)
+        ctx.getNormals(5.0 * scale, pts)
+        _, o_cnt = oc.normals(pts, 5.0 * scale, oc.F64)
+        assert np.array_equal(ctx.neighbor_counts(), o_cnt), scale
+        assert ctx.neighbor_counts()[0] == 2                               # itself and (1,1,1)*scale only
+    with pytest.raises(gm.GmError):
+        ctx.getNormals(1e-20, cloud)                                       # outside the admitted radius range
+
+
 def test_get_normals_plane_known_answer(ctx):
     nvec = np.array([1.0, 2.0, 2.0]) / 3.0
     xyz = synth.plane_patch(4000, seed=1, normal=nvec, offset=1.5, half=1.5)

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM roofline rows of the STREAMING kernels from a rocprofv3 kernel-stats CSV of one
+frame size (tools/stage_times.py under rocprofv3 --kernel-trace --stats).
+
+usage: streaming_roofline.py <kernel_stats.csv> <stage_times.log> <out.json>
+
+Algorithmic bytes follow SURVEY.md par. 8(d) (each array touched once; float4 rows counted at the
+12 B of x,y,z they carry, normals at 16 B); `bytes_moved` is what the kernel really loads/stores
+(16-byte rows).  Peak: 8.0 TB/s spec, 6.29 TB/s measured copy peak (MI355X_MICROARCH.md)."""
+import csv, json, sys
+
+stats, log, out = sys.argv[1:4]
+meta = {}
+for line in open(log):
+    if line.startswith("{"):
+        meta = json.loads(line)
+n_in, n_c, n_v = meta["points"], meta["n_cropped"], meta["n_valid"]
+dur = {}
+for r in csv.DictReader(open(stats)):
+    dur[r["Name"].split("(")[0].replace("void ", "")] = (float(r["AverageNs"]) * 1e-9, int(r["Calls"]))
+
+# kernel -> (reference step, algorithmic bytes, bytes really moved)
+rows = {
+    "gm::k_compact_count<gm::CropPred>": ("CropBox predicate pass", 12 * n_in, 12 * n_in),
+    "gm::k_compact_scatter<gm::CropPred, gm::CropEmit>": ("CropBox copy (order-preserving)", 12 * n_in + 12 * n_c, 12 * n_in + 16 * n_c + 4 * n_c),
+    "gm::k_compact_count<gm::ValidPred>": ("removeNaNNormals predicate pass", 12 * n_c, 16 * n_c),
+    "gm::k_compact_scatter<gm::ValidPred, gm::ValidEmit>": ("removeNaNNormals + ExtractIndices", 28 * n_c + 28 * n_v, 32 * n_c + 32 * n_v),
+    "gm::k_scatter_partials": ("getLocalFrame sum of (w n)(w n)^T", 16 * n_v, 16 * n_v),
+    "gm::k_label<0>": ("plane inlier labelling", 12 * n_v + n_v, 16 * n_v + n_v),
+    "gm::k_label<1>": ("cylinder inlier labelling", 12 * n_v + n_v, 16 * n_v + 2 * n_v),
+    "gm::k_segment_moments": ("per-segment covariance (points + normals of one label)", 24 * n_v + n_v, 32 * n_v + n_v),
+}
+res = {"points": n_in, "n_cropped": n_c, "n_valid": n_v, "radius": meta.get("radius"),
+       "peak_spec_GBs": 8000.0, "peak_measured_copy_GBs": 6290.0, "kernels": {}}
+for k, (what, alg, moved) in rows.items():
+    if k not in dur:
+        continue
+    t, calls = dur[k]
+    res["kernels"][k] = {"reference_step": what, "avg_us": round(t * 1e6, 2), "calls": calls,
+                         "algorithmic_bytes": alg, "algorithmic_GBs": round(alg / t / 1e9, 1),
+                         "frac_of_spec": round(alg / t / 8.0e12, 3), "frac_of_measured_peak": round(alg / t / 6.29e12, 3),
+                         "bytes_moved": moved, "moved_GBs": round(moved / t / 1e9, 1)}
+json.dump(res, open(out, "w"), indent=1)
+for k, v in res["kernels"].items():
+    print(k[:52].ljust(52), "%8.1f us %8.1f GB/s alg (%.0f %% of spec)  %8.1f GB/s moved" %
+          (v["avg_us"], v["algorithmic_GBs"], 100 * v["frac_of_spec"], v["moved_GBs"]))
