@@ -532,8 +532,10 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
         if (nb > cap) nb = cap;
         (void)concurrent;
     }
+    static const char *dl = getenv("GM_NORMALS_DYNLDS");  // experiment knob: extra LDS per block lowers the blocks per CU
+    const uint32_t dyn_lds = dl ? (uint32_t)atoi(dl) : 0u;
     hipEventRecord(sl.ev_k0, s);
-    hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), 0, s, (const float4 *)sl.spts4, (const uint32_t *)skeys,
+    hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), dyn_lds, s, (const float4 *)sl.spts4, (const uint32_t *)skeys,
                        (const uint2 *)sl.tiles, sl.ctr, g, sl.tiles_cap, (const uint2 *)sl.row_bounds, sl.normals4,
                        keep_counts ? sl.counts : (int32_t *)nullptr, vd, sl.vox_table);
     hipEventRecord(sl.ev_k1, s);

@@ -70,6 +70,25 @@ int main(int argc, char **argv)
         REQUIRE(normalsDisp[0].ns == "normals" && normalsDisp[0].frame_id == "/velodyne" && normalsDisp[0].color_b == 1.0f);
         REQUIRE(eigenBasis[2].ns == "eigenBasis" && eigenBasis[2].id == 2 && eigenBasis[0].color_r == 1.0f);
         REQUIRE(std::fabs(eigenBasis[0].points[1][0] - centerAxis(0)) < 1e-7);
+        // --- the cylinder marker (reference's displayCylinder stub): RANSAC cylinder on, tunnel R = 2 along x
+        {
+            Processor pc(5.0, 0.5, 0.5, 0.2, 0, GM_CFG_DEFAULT | GM_CFG_RANSAC_CYLINDER);
+            gm_frame_result rc = pc.processFrame(&rows[0], n, step, 0, 4, 8);
+            Marker cyl;
+            REQUIRE(Processor::rvizCylinder(rc, 10.0, cyl));
+            REQUIRE(cyl.type == MARKER_CYLINDER && cyl.ns == "cylinder" && cyl.frame_id == "/velodyne");
+            REQUIRE(std::fabs(cyl.scale[0] - 4.0) < 0.1 && cyl.scale[1] == cyl.scale[0] && cyl.scale[2] == 10.0);
+            // rotate (0,0,1) by the marker quaternion: must give the fitted axis, which is +-x here
+            const double *q = cyl.orientation;
+            const double zx = 2 * (q[0] * q[2] + q[3] * q[1]), zy = 2 * (q[1] * q[2] - q[3] * q[0]),
+                         zz = 1 - 2 * (q[0] * q[0] + q[1] * q[1]);
+            REQUIRE(std::fabs(zx - rc.cylinder[3]) < 1e-6 && std::fabs(zy - rc.cylinder[4]) < 1e-6 && std::fabs(zz - rc.cylinder[5]) < 1e-6);
+            REQUIRE(std::fabs(std::fabs(zx) - 1.0) < 0.02);
+            REQUIRE(std::sqrt(cyl.position[1] * cyl.position[1] + cyl.position[2] * cyl.position[2]) < 0.1);  // axis through the origin
+            gm_frame_result none = r;   // a frame processed without the RANSAC flag carries no cylinder
+            Marker untouched;
+            REQUIRE(!Processor::rvizCylinder(none, 10.0, untouched));
+        }
         // error conventions: a status, never a crash
         bool threw = false;
         try { proc.getLocalFrame((int)cloudNormals.size() + 1, 0.2, cloudNormals, eigenVals, eigenVecs); } catch (const std::out_of_range &) { threw = true; }

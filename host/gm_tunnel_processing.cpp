@@ -132,7 +132,32 @@ Marker Processor::rvizArrow(const Vector3f &start, const Vector3f &end, const Ve
     m.type = MARKER_ARROW; m.action = MARKER_ADD;  // :179-180
     for (int k = 0; k < 3; ++k) { m.points[0][k] = start(k); m.points[1][k] = end(k); m.scale[k] = scale(k); }
     m.color_a = color(0); m.color_r = color(1); m.color_g = color(2); m.color_b = color(3);  // :199-202: A,R,G,B
+    m.position[0] = m.position[1] = m.position[2] = 0.0;   // the reference leaves the pose default-constructed
+    m.orientation[0] = m.orientation[1] = m.orientation[2] = 0.0; m.orientation[3] = 1.0;
     return m;
+}
+
+bool Processor::rvizCylinder(const gm_frame_result &r, const double &length, Marker &m, const std::string &frame)
+{
+    const double p[3] = {r.cylinder[0], r.cylinder[1], r.cylinder[2]};
+    double d[3] = {r.cylinder[3], r.cylinder[4], r.cylinder[5]};
+    const double rad = r.cylinder[6];
+    const double dn = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (!(r.cylinder_inliers > 0) || !(dn > 0.0) || !(rad == rad)) return false;   // no cylinder this frame
+    for (int k = 0; k < 3; ++k) d[k] /= dn;
+    m.frame_id = frame; m.ns = "cylinder"; m.id = 0;
+    m.type = MARKER_CYLINDER; m.action = MARKER_ADD;
+    const double t = p[0] * d[0] + p[1] * d[1] + p[2] * d[2];
+    for (int k = 0; k < 3; ++k) { m.position[k] = p[k] - t * d[k]; m.points[0][k] = m.points[1][k] = 0.0; }
+    // shortest-arc rotation taking the marker's z axis onto d: q = (z x d, 1 + z.d), normalised
+    double q[4] = {-d[1], d[0], 0.0, 1.0 + d[2]};
+    const double qn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (qn < 1e-12) { q[0] = 1.0; q[1] = q[2] = q[3] = 0.0; }   // d = -z: half turn about x
+    else for (int k = 0; k < 4; ++k) q[k] /= qn;
+    for (int k = 0; k < 4; ++k) m.orientation[k] = q[k];
+    m.scale[0] = m.scale[1] = 2.0 * rad; m.scale[2] = length;
+    m.color_a = 0.3f; m.color_r = 0.0f; m.color_g = 1.0f; m.color_b = 1.0f;
+    return true;
 }
 
 MarkerArray Processor::rvizNormals(const double &leafSize, const PointCloud &cloud, const NormalCloud &nrm)

@@ -40,9 +40,10 @@ struct Marker {
     double points[2][3];
     double scale[3];
     float color_a, color_r, color_g, color_b;
+    double position[3], orientation[4];                   // pose (x,y,z,w); identity for the reference's arrows
 };
 typedef std::vector<Marker> MarkerArray;
-enum { MARKER_ARROW = 0, MARKER_ADD = 0 };                // visualization_msgs::Marker::ARROW / ADD
+enum { MARKER_ARROW = 0, MARKER_CYLINDER = 3, MARKER_ADD = 0 };   // visualization_msgs::Marker::ARROW / CYLINDER / ADD
 
 class Error : public std::runtime_error {
 public:
@@ -81,6 +82,13 @@ public:
                             const std::string &ns, const int &id = 0, const std::string &frame = "/velodyne");
     MarkerArray rvizNormals(const double &leafSize, const PointCloud &cloud, const NormalCloud &normals);
     static MarkerArray rvizEigens(const Vector3f &eigenVals, const Matrix3f &eigenVecs);
+    // The reference's unfinished cylinder output (getCylinder stub src/tunnel_processing.cpp:149-154, publisher
+    // "centerAxisOutput" of type Marker src/geometric_mapping.cpp:41,119-121,163-165, param displayCylinder
+    // launch/mapping.launch:15): one CYLINDER marker from gm_frame_result.cylinder (needs GM_CFG_RANSAC_CYLINDER),
+    // centred on the axis point nearest the sensor origin, z axis along the fitted axis, `length` metres long.
+    // Returns false (marker untouched) when the frame produced no cylinder.
+    static bool rvizCylinder(const gm_frame_result &result, const double &length, Marker &marker,
+                             const std::string &frame = "/velodyne");
 
     gm_ctx *ctx() { return ctx_; }
 

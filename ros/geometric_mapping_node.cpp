@@ -9,6 +9,10 @@
 //   pub        "eigenBasisOutput" visualization_msgs/MarkerArray, queue 10, if displayCenterAxis (:159-161)
 //   params     boxFilterBound voxelGridLeafSize neighborRadius weightingFactor
 //              displayCloud displayNormals displayCenterAxis usePCLViz   (src/paramHandler.cpp:12-66)
+//   pub        "centerAxisOutput" visualization_msgs/Marker, queue 10, if displayCylinder -- the reference declares
+//              this publisher and parameter but leaves them commented out (:41,119-121,163-165,
+//              src/paramHandler.cpp:55-58, launch/mapping.launch:15 sets displayCylinder=false); here the
+//              parameter is honoured: it switches the RANSAC cylinder fit on and publishes one CYLINDER marker
 // and replaces the PCL/Eigen arithmetic of cloud_cb (:48-125) with ONE call into
 // the C ABI (gm_process_frame reads the PointCloud2 rows directly: no pcl::fromROSMsg).
 //
@@ -34,7 +38,7 @@ namespace {
 
 struct Parameters {  // mirrors class Parameters, include/geometric_mapping/paramHandler.hpp:9-37
     double boxFilterBound = 5.0, leafSize = .1, neighborRadius = .03, weightingFactor = .2;
-    bool rvizCloud = true, rvizNormals = true, rvizCenterAxis = true, pclviz = false;
+    bool rvizCloud = true, rvizNormals = true, rvizCenterAxis = true, pclviz = false, rvizCylinder = false;
     explicit Parameters(ros::NodeHandle &node)
     {
         // global names, read once (src/paramHandler.cpp:13-65); log text kept
@@ -50,12 +54,13 @@ struct Parameters {  // mirrors class Parameters, include/geometric_mapping/para
         node.getParam("displayNormals", rvizNormals);
         node.getParam("displayCenterAxis", rvizCenterAxis);
         node.getParam("usePCLViz", pclviz);
+        node.getParam("displayCylinder", rvizCylinder);
     }
 };
 
 std::unique_ptr<Parameters> params;
 std::unique_ptr<gm_host::Processor> proc;
-ros::Publisher cloudPub, normalsPub, centerAxisPub;
+ros::Publisher cloudPub, normalsPub, centerAxisPub, cylinderPub;
 
 bool find_xyz(const sensor_msgs::PointCloud2 &m, unsigned &ox, unsigned &oy, unsigned &oz)
 {
@@ -69,24 +74,32 @@ bool find_xyz(const sensor_msgs::PointCloud2 &m, unsigned &ox, unsigned &oy, uns
     return fx && fy && fz;
 }
 
+visualization_msgs::Marker to_ros(const gm_host::Marker &s)
+{
+    visualization_msgs::Marker m;
+    m.header.frame_id = s.frame_id;
+    m.header.stamp = ros::Time::now();  // src/tunnel_processing.cpp:175 (not the input stamp)
+    m.header.seq = 0;
+    m.ns = s.ns; m.id = s.id;
+    m.type = s.type;                    // ARROW = 0, CYLINDER = 3: same values as visualization_msgs::Marker
+    m.action = visualization_msgs::Marker::ADD;
+    if (s.type == gm_host::MARKER_ARROW) {
+        m.points.resize(2);
+        for (int k = 0; k < 2; ++k) { m.points[k].x = s.points[k][0]; m.points[k].y = s.points[k][1]; m.points[k].z = s.points[k][2]; }
+    }
+    m.pose.position.x = s.position[0]; m.pose.position.y = s.position[1]; m.pose.position.z = s.position[2];
+    m.pose.orientation.x = s.orientation[0]; m.pose.orientation.y = s.orientation[1];
+    m.pose.orientation.z = s.orientation[2]; m.pose.orientation.w = s.orientation[3];
+    m.scale.x = s.scale[0]; m.scale.y = s.scale[1]; m.scale.z = s.scale[2];
+    m.color.a = s.color_a; m.color.r = s.color_r; m.color.g = s.color_g; m.color.b = s.color_b;
+    return m;
+}
+
 visualization_msgs::MarkerArray to_ros(const gm_host::MarkerArray &in)
 {
     visualization_msgs::MarkerArray out;
     out.markers.resize(in.size());
-    for (size_t i = 0; i < in.size(); ++i) {
-        visualization_msgs::Marker &m = out.markers[i];
-        const gm_host::Marker &s = in[i];
-        m.header.frame_id = s.frame_id;
-        m.header.stamp = ros::Time::now();  // src/tunnel_processing.cpp:175 (not the input stamp)
-        m.header.seq = 0;
-        m.ns = s.ns; m.id = s.id;
-        m.type = visualization_msgs::Marker::ARROW;
-        m.action = visualization_msgs::Marker::ADD;
-        m.points.resize(2);
-        for (int k = 0; k < 2; ++k) { m.points[k].x = s.points[k][0]; m.points[k].y = s.points[k][1]; m.points[k].z = s.points[k][2]; }
-        m.scale.x = s.scale[0]; m.scale.y = s.scale[1]; m.scale.z = s.scale[2];
-        m.color.a = s.color_a; m.color.r = s.color_r; m.color.g = s.color_g; m.color.b = s.color_b;
-    }
+    for (size_t i = 0; i < in.size(); ++i) out.markers[i] = to_ros(in[i]);
     return out;
 }
 
@@ -135,6 +148,10 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input)
     }
     if (params->rvizCenterAxis)  // :114-117
         centerAxisPub.publish(to_ros(gm_host::Processor::rvizEigens(vals, vecs)));
+    if (params->rvizCylinder) {  // the reference's commented-out block :119-121
+        gm_host::Marker cyl;
+        if (gm_host::Processor::rvizCylinder(r, 2.0 * params->boxFilterBound, cyl)) cylinderPub.publish(to_ros(cyl));
+    }
     ROS_INFO("Published...");
 }
 
@@ -149,7 +166,8 @@ int main(int argc, char **argv)
     if (params->pclviz) ROS_WARN("usePCLViz is ignored by the MI355X host (no PCL in this build)");
     try {
         proc.reset(new gm_host::Processor(params->boxFilterBound, params->leafSize, params->neighborRadius,
-                                          params->weightingFactor));
+                                          params->weightingFactor, 0,
+                                          GM_CFG_DEFAULT | (params->rvizCylinder ? GM_CFG_RANSAC_CYLINDER : 0u)));
     } catch (const gm_host::Error &e) {
         ROS_FATAL("libgm_hip: %s", e.what());
         return 1;
@@ -158,6 +176,7 @@ int main(int argc, char **argv)
     if (params->rvizCloud) cloudPub = node.advertise<sensor_msgs::PointCloud2>("cloudOutput", 10);
     if (params->rvizNormals) normalsPub = node.advertise<visualization_msgs::MarkerArray>("normalsOutput", 10);
     if (params->rvizCenterAxis) centerAxisPub = node.advertise<visualization_msgs::MarkerArray>("eigenBasisOutput", 10);
+    if (params->rvizCylinder) cylinderPub = node.advertise<visualization_msgs::Marker>("centerAxisOutput", 10);  // :165
     ros::spin();
     proc.reset();
     return 0;
