@@ -501,16 +501,18 @@ __global__ __launch_bounds__(256) void k_frame_moments(const float4 *__restrict_
     for (int k = 0; k < 10; ++k) a[k] = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) b[k] = 0;
+    // loads are unconditional (label, point, normal: three coalesced streams) so that the unrolled trips keep
+    // twelve loads per lane in flight; only the fp64 accumulation is predicated on the label
+#pragma unroll 4
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t l = labels[i];
-        if (l != 1u && l != 2u) continue;
         const float4 p = pts[i];
+        const float4 q = nrm[i];
         const double x = p.x, y = p.y, z = p.z;
         if (l == 1u) {
             a[0] += 1.0; a[1] += x; a[2] += y; a[3] += z;
             a[4] += x * x; a[5] += x * y; a[6] += x * z; a[7] += y * y; a[8] += y * z; a[9] += z * z;
-        } else {
-            const float4 q = nrm[i];
+        } else if (l == 2u) {
             const double u = q.x, v = q.y, w = q.z;
             b[0] += 1.0; b[1] += x; b[2] += y; b[3] += z;
             b[4] += x * x; b[5] += x * y; b[6] += x * z; b[7] += y * y; b[8] += y * z; b[9] += z * z;

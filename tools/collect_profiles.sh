@@ -15,3 +15,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $ARGS > $OUT/bench_write.log 2>&1 || exit 3
 cd $ROOT
 python3 tools/summarize_profiles.py $OUT $TAG
+# 10 M-point frame (BASELINE configs[2]: plane + cylinder RANSAC): per-kernel durations for the streaming-kernel roofline rows
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace10m -- python3 $ROOT/tools/stage_times.py --points 10000000 --flags 12 --reps 5 > $OUT/stage10m.log 2>&1 || exit 4
+cd $ROOT
+python3 tools/streaming_roofline.py "$(ls $OUT/trace10m/*/*kernel_stats.csv | tail -1)" $OUT/stage10m.log $OUT/summary/${TAG}_streaming_kernels_10M.json

@@ -29,6 +29,7 @@ rows = {
     "gm::k_label<0>": ("plane inlier labelling", 12 * n_v + n_v, 16 * n_v + n_v),
     "gm::k_label<1>": ("cylinder inlier labelling", 12 * n_v + n_v, 16 * n_v + 2 * n_v),
     "gm::k_segment_moments": ("per-segment covariance (points + normals of one label)", 24 * n_v + n_v, 32 * n_v + n_v),
+    "gm::k_frame_moments": ("per-segment covariance, both segments in one pass (labels + points; normals of cylinder inliers)", 12 * n_v + n_v, 32 * n_v + n_v),
 }
 res = {"points": n_in, "n_cropped": n_c, "n_valid": n_v, "radius": meta.get("radius"),
        "peak_spec_GBs": 8000.0, "peak_measured_copy_GBs": 6290.0, "kernels": {}}
