@@ -115,17 +115,30 @@ __global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict
     const int w = threadIdx.x / kWave;
     // a point starts a tile iff it starts a 64-chunk of its x-row, or its chunk is "sparse"
     // (spans more than `span` cell steps) and it is the first point of an aligned cell group
-    uint32_t cnt = 0, cend = 0;
+    uint32_t cnt = 0, tend = 0;
     if (s < n) {
         const uint32_t key = skeys[s];
         const uint32_t row = key / nx;
         const uint2 rb = row_bounds[row];  // written by k_gather_sorted
         const uint32_t cstart = rb.x + ((s - rb.x) / (uint32_t)kTileQ) * (uint32_t)kTileQ;
-        cend = (cstart + kTileQ < rb.y) ? cstart + kTileQ : rb.y;
+        const uint32_t cend = (cstart + kTileQ < rb.y) ? cstart + kTileQ : rb.y;
+        const bool sparse = skeys[cend - 1] - skeys[cstart] > span;  // same row: key difference = cell steps
+        const uint32_t group = span + 1u;
+        const uint32_t my_group = (key - row * nx) / group;
         if (s == cstart) cnt = 1;
-        else if (skeys[cend - 1] - skeys[cstart] > span) {  // same row: key difference = cell steps
-            const uint32_t group = span + 1u;
-            if ((key - row * nx) / group != (skeys[s - 1] - row * nx) / group) cnt = 1;
+        else if (sparse && my_group != (skeys[s - 1] - row * nx) / group) cnt = 1;
+        if (cnt) {
+            // the tile ends with its 64-chunk or, in a sparse chunk, where the next cell group begins
+            // (keys ascend inside a row: a short binary search, on the rare sparse chunks only)
+            tend = cend;
+            if (sparse) {
+                uint32_t lo = s + 1, hi = cend;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((skeys[mid] - row * nx) / group == my_group) lo = mid + 1; else hi = mid;
+                }
+                tend = lo;
+            }
         }
     }
     // block-wide exclusive prefix of the flags, ONE atomic per block for the base
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict
     if (threadIdx.x == 0) block_base = total ? atomicAdd(&ctr->n_tiles, total) : 0u;
     __syncthreads();
     const uint32_t t_out = block_base + woff + inc - cnt;
-    if (cnt && t_out < tiles_cap) tiles[t_out] = make_uint2(s, cend);  // start, end of its 64-chunk
+    if (cnt && t_out < tiles_cap) tiles[t_out] = make_uint2(s, tend - s);  // first query, number of queries
 }
 
 // ---- smallest eigenpair of a symmetric PSD 3x3, fp64 ----------------------------
@@ -232,36 +245,19 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
         const uint32_t t = wave_id + iter * n_waves;
         if (t >= ntiles) break;  // every wave reaches this: the tile list is final before the launch
         const uint2 tile = tiles[t];
-        const uint32_t qs = tile.x, cend = tile.y;
-        // the tile = points from qs up to the end of its 64-chunk or, in a sparse chunk, of its cell group
-        const uint32_t ka = skeys[qs];
-        uint32_t qn;
-        {
-            const uint32_t rowa = ka / (uint32_t)g.nx;
-            const uint32_t rstart = row_bounds[rowa].x;
-            const uint32_t cstart = rstart + ((qs - rstart) / (uint32_t)kTileQ) * (uint32_t)kTileQ;
-            const uint32_t span = (uint32_t)(kTileSpan * (g.xreach - 1));
-            const bool sparse = skeys[cend - 1] - skeys[cstart] > span;
-            const uint32_t group = span + 1u;
-            bool mine = qs + lane < cend;
-            if (mine && sparse) {
-                const uint32_t kl = skeys[qs + lane];
-                mine = (kl - rowa * (uint32_t)g.nx) / group == (ka - rowa * (uint32_t)g.nx) / group;
-            }
-            const uint64_t mask = __ballot(mine);
-            qn = (~mask == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~mask);  // same-group lanes are contiguous from lane 0
-        }
-
-        // tile geometry: one x-row
-        const uint32_t row = ka / (uint32_t)g.nx;
-        const int cy = (int)(row % (uint32_t)g.ny), cz = (int)(row / (uint32_t)g.ny);
+        const uint32_t qs = tile.x, qn = tile.y;  // first query (sorted position), number of queries (1..64)
 
         // this lane's query and its fine x cell (keys inside a tile are ascending: lanes are x-sorted)
         const int ql = lane;
         const bool active = (uint32_t)ql < qn;
         const uint32_t qidx = qs + (active ? (uint32_t)ql : qn - 1u);
         const float4 q = spts4[qidx];
-        const int fxl = (int)(skeys[qidx] - row * (uint32_t)g.nx);
+        const uint32_t kl = skeys[qidx];
+        // tile geometry: one x-row (lane 0 holds the tile's first query)
+        const uint32_t ka = __builtin_amdgcn_readfirstlane(kl);
+        const uint32_t row = ka / (uint32_t)g.nx;
+        const int cy = (int)(row % (uint32_t)g.ny), cz = (int)(row / (uint32_t)g.ny);
+        const int fxl = (int)(kl - row * (uint32_t)g.nx);
         // slab sharding: a tile made only of halo points (outside this rank's x range) produces no output
         if (__ballot(active && q.x >= vd.own_lo && q.x < vd.own_hi) == 0) {
             if (active) {
@@ -278,24 +274,33 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
         // walk their own window in lock-step (different LDS addresses, broadcast inside a group), so the
         // loop runs for the longest group window (~2.4 cell edges) instead of the tile's (~3.4).
         const int gi = lane / kGroupLanes;  // (inactive lanes repeat the tile's last query, so group intervals stay valid)
-        // 9 rows x kGroups groups x {begin,end}: binary searches in the sorted keys, spread over the lanes
-        uint32_t sres[2] = {0, 0};
-#pragma unroll
-        for (int rnd = 0; rnd < 2; ++rnd) {
-            const int i = lane + rnd * kWave;       // slot i = kind*36 + r*4 + group   (kGroups == 4)
-            const bool work = i < 2 * 9 * kGroups;
-            const int ii = work ? i : 0;
-            const int kind = ii / (9 * kGroups), rem = ii % (9 * kGroups), r = rem / kGroups, gg = rem % kGroups;
+        // 9 rows x kGroups groups: lane i < 36 finds BOTH ends of the window of (row i / 4, group i % 4) by two
+        // binary searches that run in the same loop (two independent loads in flight per step) and only inside
+        // the row's own range [row_bounds.x, row_bounds.y): ~log2(points of the row) dependent steps per tile
+        // instead of 2 x log2(n).  Unoccupied rows have row_bounds = (0, 0) (cleared per frame): empty window.
+        uint32_t sb = 0, se = 0;
+        {
+            const int slot = lane < 9 * kGroups ? lane : 0;
+            const int r = slot / kGroups, gg = slot % kGroups;
             // x interval of lane group gg (shuffles run with every lane active)
             const int lo_fx = __shfl(fxl, gg * kGroupLanes, kWave);
             const int hi_fx = __shfl(fxl, gg * kGroupLanes + kGroupLanes - 1, kWave);
             const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
-            if (work && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-                const uint32_t rbk = (uint32_t)((zz * g.ny + yy) * g.nx);
+            if (lane < 9 * kGroups && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                const uint32_t nrow = (uint32_t)(zz * g.ny + yy);
+                const uint2 rb = row_bounds[nrow];
+                const uint32_t rbk = nrow * (uint32_t)g.nx;
                 const int xa = lo_fx > g.xreach ? lo_fx - g.xreach : 0;
                 const int xb = hi_fx + g.xreach < g.nx - 1 ? hi_fx + g.xreach : g.nx - 1;
-                sres[rnd] = kind == 0 ? lower_bound_u32(skeys, n, rbk + (uint32_t)xa)
-                                      : lower_bound_u32(skeys, n, rbk + (uint32_t)xb + 1u);
+                const uint32_t key_b = rbk + (uint32_t)xa, key_e = rbk + (uint32_t)xb + 1u;
+                uint32_t lo1 = rb.x, hi1 = rb.y, lo2 = rb.x, hi2 = rb.y;
+                while (lo1 < hi1 || lo2 < hi2) {
+                    const uint32_t m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
+                    const uint32_t k1 = skeys[m1 < n ? m1 : n - 1u], k2 = skeys[m2 < n ? m2 : n - 1u];
+                    if (lo1 < hi1) { if (k1 < key_b) lo1 = m1 + 1u; else hi1 = m1; }
+                    if (lo2 < hi2) { if (k2 < key_e) lo2 = m2 + 1u; else hi2 = m2; }
+                }
+                sb = lo1; se = lo2;
             }
         }
 
@@ -326,11 +331,8 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
         // ---- chunk iterator over the 9 row ranges (row-wide range = begin of the lowest-x group .. end of
         // the highest-x group), software-pipelined: the global loads of chunk i+1 are in flight (in registers)
         // while chunk i is consumed from LDS
-        auto row_begin = [&](int r) -> uint32_t { return __builtin_amdgcn_readlane(sres[0], r * kGroups); };
-        auto row_end = [&](int r) -> uint32_t {
-            const int je = 9 * kGroups + r * kGroups + (kGroups - 1);
-            return je < kWave ? __builtin_amdgcn_readlane(sres[0], je) : __builtin_amdgcn_readlane(sres[1], je - kWave);
-        };
+        auto row_begin = [&](int r) -> uint32_t { return __builtin_amdgcn_readlane(sb, r * kGroups); };
+        auto row_end = [&](int r) -> uint32_t { return __builtin_amdgcn_readlane(se, r * kGroups + (kGroups - 1)); };
         int nr = 0;                       // next chunk: row index, start, length (0 = none left)
         uint32_t nc0 = 0, nlen = 0;
         auto seek = [&](int r, uint32_t c) {  // first non-empty chunk at or after (r, c)
@@ -361,10 +363,7 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
             wave_lds_fence();
             if (c0 + clen < row_end(r)) seek(r, c0 + clen); else seek(r + 1, r + 1 < 9 ? row_begin(r + 1) : 0u);
             // my group's window inside this chunk (clamped), start aligned down to 4 for ds_read_b128
-            const int sb_slot = r * kGroups + gi, se_slot = 9 * kGroups + r * kGroups + gi;
-            const uint32_t mb = __shfl(sres[0], sb_slot, kWave);
-            const uint32_t me_a = __shfl(sres[0], se_slot & (kWave - 1), kWave), me_b = __shfl(sres[1], se_slot & (kWave - 1), kWave);
-            const uint32_t me = se_slot < kWave ? me_a : me_b;
+            const uint32_t mb = __shfl(sb, r * kGroups + gi, kWave), me = __shfl(se, r * kGroups + gi, kWave);
             uint32_t ob = mb > c0 ? mb - c0 : 0u, oe = me > c0 ? me - c0 : 0u;
             if (ob > clen) ob = clen;
             if (oe > clen) oe = clen;
@@ -517,6 +516,8 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     uint32_t *perm = where ? sl.vals_b : sl.vals_a;
     sl.skeys = skeys;
     const uint32_t gb = (n_cap + 255) / 256 < 2048 ? (n_cap + 255) / 256 : 2048;
+    // rows the frame leaves unoccupied must read as empty ranges in k_normals' window searches
+    hipMemsetAsync(sl.row_bounds, 0, sizeof(uint2) * (size_t)g.ny * (size_t)g.nz, s);
     hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(256), 0, s, (const float4 *)sl.crop4, (const uint32_t *)perm,
                        (const uint32_t *)skeys, (const uint32_t *)&sl.ctr->n_cropped, (uint32_t)g.nx, sl.spts4,
                        sl.row_bounds);
