@@ -172,3 +172,47 @@ def test_frame_ransac_cylinder_only_is_deterministic(gm):
     assert a["cylinder_inliers"] == b["cylinder_inliers"] and np.array_equal(a["cylinder"], b["cylinder"])
     assert a["plane_inliers"] == 0 and np.isnan(a["plane"]).all()
     assert abs(a["cylinder"][6] - 2.0) < 0.05
+
+
+def test_full_size_properties_10m_plane_and_cylinder(gm, oc):
+    """BASELINE configs[2]: 10 M-point frame, plane + cylinder models, one GPU.  Too large for the oracle's normals in
+    seconds, so the check is through size-independent properties: exact crop count and order, unit normals, label
+    counts that add up, the labelling re-derived by the oracle's O(n) label pass from the reported models, analytic
+    truth of the generator, and linearity of the segment moments."""
+    from geometric_mapping_amd import _lib
+    n = 10_000_000
+    xyz = synth.tunnel_frame(n, seed=3, floor_z=-1.2, outlier_frac=0.01)
+    flags = _lib.GM_CFG_DEFAULT | _lib.GM_CFG_RANSAC_PLANE | _lib.GM_CFG_RANSAC_CYLINDER
+    with gm.GeometricMapping(neighborRadius=synth.fixed_k_radius(n), flags=flags, ransac_hypotheses=1024,
+                             ransac_threshold=TAU, ransac_seed=5, max_points=n) as c:
+        res = c.process_frame(xyz)
+        cloud, rows = c.cropped_cloud()
+        nrm = c.normals()
+        lab = c.labels()
+        res2 = c.process_frame(xyz)
+        lab2 = c.labels()
+    inside = np.all(np.abs(xyz) <= 5.0, axis=1)
+    assert res["n_cropped"] == int(inside.sum())
+    assert np.all(np.diff(rows.astype(np.int64)) > 0) and np.array_equal(xyz[rows], cloud)
+    assert res["n_valid"] == len(cloud) == len(nrm) == len(lab)
+    assert np.abs(np.linalg.norm(nrm[:, :3].astype(np.float64), axis=1) - 1).max() < 1e-6
+    # labels: counts add up, and the oracle's label pass over the same models reproduces them bit for bit
+    assert int((lab == 1).sum()) == res["plane_inliers"] and int((lab == 2).sum()) == res["cylinder_inliers"]
+    labels = np.zeros(len(cloud), np.uint8)
+    assert oc.label_plane(cloud, labels, 0, 1, res["plane"], TAU) == res["plane_inliers"]
+    assert oc.label_cylinder(cloud, labels, 0, 2, res["cylinder"], TAU) == res["cylinder_inliers"]
+    assert np.array_equal(lab, labels)
+    # analytic truth: floor z = -1.2, tunnel R = 2 along x
+    assert abs(abs(res["plane_refit"][2]) - 1) < 1e-4 and abs(abs(res["plane_refit"][3]) - 1.2) < 2e-3
+    assert abs(res["cylinder"][6] - 2.0) < 0.05 and ang(res["cylinder"][3:6], [1, 0, 0]) < 0.05
+    assert ang(res["cylinder_axis_refit"], [1, 0, 0]) < 2e-3 and ang(res["center_axis"], [1, 0, 0]) < 5e-3
+    # (floor = 29.5 % of the ring; the cylinder model is the best of 1024 two-point hypotheses whose normals come from
+    # 3.5 cm neighbourhoods of sigma = 1 cm points, so it holds about half of the wall, not all of it)
+    assert res["plane_inliers"] > 0.25 * len(cloud) and res["cylinder_inliers"] > 0.3 * len(cloud)
+    # refits equal the oracle's on the device's own labels (fp64 sums over 8 M points: order differs)
+    pr = oc.refit_plane(oc.segment_moments(cloud, nrm, lab, 1))
+    assert min(np.abs(res["plane_refit"] - pr).max(), np.abs(res["plane_refit"] + pr).max()) < 1e-8
+    assert ang(res["cylinder_axis_refit"], oc.refit_axis(oc.segment_moments(cloud, nrm, lab, 2))) < 1e-8
+    # determinism at full size
+    assert np.array_equal(lab, lab2) and res2["plane_inliers"] == res["plane_inliers"]
+    assert np.array_equal(res2["scatter"], res["scatter"]) and np.array_equal(res2["cylinder"], res["cylinder"])
