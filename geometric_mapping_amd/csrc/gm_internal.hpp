@@ -100,7 +100,6 @@ void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const Gr
 // Returns 0 if the sorted data ends in (keys_a, vals_a), 1 if in (keys_b, vals_b).
 int launch_radix_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
                       const uint32_t *n_ptr, uint32_t n_cap, int key_bits, SortScratch &sc, hipStream_t s);
-void launch_exclusive_scan(uint32_t *data, uint32_t count, uint32_t *total_out, uint32_t *total_out2, hipStream_t s);
 uint32_t radix_hist_entries(uint32_t n_cap);
 // k_normals.hip
 void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, uint32_t n_cap, bool keep_counts,

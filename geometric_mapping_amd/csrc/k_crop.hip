@@ -71,44 +71,6 @@ struct CropEmit {
     }
 };
 
-__global__ __launch_bounds__(1024) void k_exclusive_scan(uint32_t *__restrict__ data, uint32_t count,
-                                                         uint32_t *__restrict__ total_out,
-                                                         uint32_t *__restrict__ total_out2)
-{
-    __shared__ uint32_t wtot[1024 / kWave];
-    const uint32_t per = (count + 1023u) / 1024u;
-    const uint32_t b = threadIdx.x * per;
-    const uint32_t e = (b + per < count) ? b + per : count;
-    uint32_t sum = 0;
-    for (uint32_t i = b; i < e; ++i) sum += data[i];
-    uint32_t inc = wave_inclusive_scan(sum);
-    const int w = threadIdx.x / kWave;
-    if (lane_id() == kWave - 1) wtot[w] = inc;
-    __syncthreads();
-    uint32_t woff = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < 1024 / kWave; ++k) {
-        uint32_t c = wtot[k];
-        if (k < w) woff += c;
-        total += c;
-    }
-    uint32_t run = woff + inc - sum;
-    for (uint32_t i = b; i < e; ++i) {
-        uint32_t v = data[i];
-        data[i] = run;
-        run += v;
-    }
-    if (threadIdx.x == 0) {
-        if (total_out) *total_out = total;
-        if (total_out2) *total_out2 = total;
-    }
-}
-
-void launch_exclusive_scan(uint32_t *data, uint32_t count, uint32_t *total_out, uint32_t *total_out2, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, data, count, total_out, total_out2);
-}
-
 void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const GridParams &g, Slot &sl, hipStream_t s)
 {
     const uint32_t nb = compact_blocks(n);
@@ -118,9 +80,8 @@ void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const Gr
     CropEmit emit{rd, g, sl.crop4, sl.keys_a};
     hipLaunchKernelGGL(k_compact_count<CropPred>, dim3(nb), dim3(kCpThreads), 0, s, pred,
                        (const uint32_t *)nullptr, n, sl.blk);
-    launch_exclusive_scan(sl.blk, nb, &sl.ctr->n_cropped, nullptr, s);
     hipLaunchKernelGGL((k_compact_scatter<CropPred, CropEmit>), dim3(nb), dim3(kCpThreads), 0, s, pred, emit,
-                       (const uint32_t *)nullptr, n, (const uint32_t *)sl.blk);
+                       (const uint32_t *)nullptr, n, (const uint32_t *)sl.blk, nb, &sl.ctr->n_cropped, (uint32_t *)nullptr);
 }
 
 }  // namespace gm

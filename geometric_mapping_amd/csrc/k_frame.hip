@@ -96,9 +96,8 @@ void launch_compact_valid(Slot &sl, uint32_t n_cap, float own_lo, float own_hi, 
     ValidEmit emit{sl.normals4, sl.crop4, sl.valid4, sl.vnorm4};
     hipLaunchKernelGGL(k_compact_count<ValidPred>, dim3(nb), dim3(kCpThreads), 0, s, pred,
                        (const uint32_t *)&sl.ctr->n_cropped, 0u, sl.blk);
-    launch_exclusive_scan(sl.blk, nb, &sl.ctr->n_valid, &sl.ctr->vox_n, s);
     hipLaunchKernelGGL((k_compact_scatter<ValidPred, ValidEmit>), dim3(nb), dim3(kCpThreads), 0, s, pred, emit,
-                       (const uint32_t *)&sl.ctr->n_cropped, 0u, (const uint32_t *)sl.blk);
+                       (const uint32_t *)&sl.ctr->n_cropped, 0u, (const uint32_t *)sl.blk, nb, &sl.ctr->n_valid, &sl.ctr->vox_n);
 }
 
 // ---- scatter matrix: streaming pass ---------------------------------------------

@@ -120,9 +120,8 @@ void launch_voxel_dense_finalize(const VoxDense &vd, Slot &sl, hipStream_t s)
     DenseEmit emit{sl.vox_table, sl.vox4, (double)vd.lo, vd.inv_scale};
     hipLaunchKernelGGL(k_compact_count<DensePred>, dim3(nb), dim3(kCpThreads), 0, s, pred, (const uint32_t *)nullptr,
                        cells, sl.blk);
-    launch_exclusive_scan(sl.blk, nb, &sl.ctr->n_voxels, nullptr, s);
     hipLaunchKernelGGL((k_compact_scatter<DensePred, DenseEmit>), dim3(nb), dim3(kCpThreads), 0, s, pred, emit,
-                       (const uint32_t *)nullptr, cells, (const uint32_t *)sl.blk);
+                       (const uint32_t *)nullptr, cells, (const uint32_t *)sl.blk, nb, &sl.ctr->n_voxels, (uint32_t *)nullptr);
 }
 
 void launch_voxel_grid(Slot &sl, uint32_t n_cap, float leaf, int key_bits, hipStream_t s)
@@ -142,9 +141,8 @@ void launch_voxel_grid(Slot &sl, uint32_t n_cap, float leaf, int key_bits, hipSt
     HeadEmit emit{sl.seg_start};
     hipLaunchKernelGGL(k_compact_count<HeadPred>, dim3(nb), dim3(kCpThreads), 0, s, pred,
                        (const uint32_t *)&sl.ctr->vox_n, 0u, sl.blk);
-    launch_exclusive_scan(sl.blk, nb, &sl.ctr->n_voxels, nullptr, s);
     hipLaunchKernelGGL((k_compact_scatter<HeadPred, HeadEmit>), dim3(nb), dim3(kCpThreads), 0, s, pred, emit,
-                       (const uint32_t *)&sl.ctr->vox_n, 0u, (const uint32_t *)sl.blk);
+                       (const uint32_t *)&sl.ctr->vox_n, 0u, (const uint32_t *)sl.blk, nb, &sl.ctr->n_voxels, (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_voxel_centroids, dim3(gb), dim3(256), 0, s, (const float4 *)sl.valid4, perm,
                        (const uint32_t *)sl.seg_start, (const DevCounters *)sl.ctr, sl.vox4);
 }
