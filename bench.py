@@ -255,6 +255,21 @@ def main():
                 traffic = pj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # the kernel's real bound: fp32 VALU issue.  Busy fraction from committed PMC counters (same workload); the
+    # live part is the lane-operation rate implied by the instruction count of that profile and THIS run's duration.
+    valu = None
+    vprof = os.path.join(ROOT, "profiles", "r01_normals_valu_pmc.json")
+    if os.path.exists(vprof) and traffic is not None:
+        try:
+            with open(vprof) as f:
+                vj = json.load(f)
+            insts = float(vj["counters"]["SQ_INSTS_VALU"])
+            valu = {"valu_busy_frac_pmc": vj["derived"]["valu_busy_frac"], "SQ_INSTS_VALU_per_launch": insts,
+                    "wave_instr_per_s": insts / (k_ms_excl * 1e-3) if k_ms_excl else None,
+                    "peak_wave_instr_per_s_packed": 1024 * 2.4e9 / 4.0,
+                    "source": "profiles/r01_normals_valu_pmc.json, profiles/r01_valu_rate_probe.txt"}
+        except Exception:
+            valu = None
 
     if rank == 0:
         out = {
@@ -271,7 +286,7 @@ def main():
             "roofline": {"kernel": "k_normals", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": k_ms, "avg_launch_ms_exclusive": k_ms_excl,
-                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "algorithmic_bytes_per_launch": algo_bytes, "valu": valu,
                          "note": "VALU-bound neighbour loop (k~256): HBM fraction is reported as the contract asks, see "
                                  "DESIGN.md par. 4 for its VALU roofline. avg_launch_ms is hipEvent-bracketed inside the timed "
                                  "region, where the kernel shares the chip with the other frames in flight; "
