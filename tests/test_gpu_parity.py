@@ -325,3 +325,33 @@ def test_full_size_properties_1m(gm):
         _, _, Ma = c2.getLocalFrame(h, WF, nrm[:h])
         _, _, Mb = c2.getLocalFrame(len(nrm) - h, WF, nrm[h:])
     assert np.abs((Ma + Mb) - M).max() / np.abs(M).max() < 1e-12
+
+
+def test_normals_grid_stride_path_is_bitwise_identical(gm):
+    """Frames beyond 262 144 tiles (~16 M points) make each wave of k_normals walk several tiles (grid-stride).  No test
+    frame is that large, so the path is forced on a small frame by capping the grid (GM_NORMALS_BLOCKS, read once per
+    process -> a child process): which wave computes a tile must not change a single bit."""
+    import subprocess, sys, tempfile, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import geometric_mapping_amd as g\n"
+        "from geometric_mapping_amd import synth\n"
+        "xyz = synth.tunnel_frame(120000, seed=9, floor_z=-1.2, outlier_frac=0.01)\n"
+        "with g.GeometricMapping(neighborRadius=0.25) as c:\n"
+        "    res = c.process_frame(xyz)\n"
+        "    np.savez(sys.argv[1], nrm=c.normals(), cloud=c.cropped_cloud()[0], scatter=res['scatter'], cen=c.voxel_centroids()[0])\n"
+    ) % root
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for tag, blocks in (("all", None), ("capped", "7")):
+            env = dict(os.environ)
+            env.pop("GM_NORMALS_BLOCKS", None)
+            if blocks:
+                env["GM_NORMALS_BLOCKS"] = blocks
+            f = os.path.join(d, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr
+            outs.append(dict(np.load(f)))
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k

@@ -18,7 +18,8 @@ def test_host_mirror_keeps_reference_function_names():
     for name in ("chopCloud", "getNormals", "getLocalFrame", "rvizArrow", "rvizNormals", "rvizEigens"):
         assert name in hdr, name
     node = open(os.path.join(ROOT, "ros", "geometric_mapping_node.cpp")).read()
-    for s in ('"input", 1', '"cloudOutput", 10', '"normalsOutput", 10', '"eigenBasisOutput", 10', "geometric_mapping_node",
+    for s in ('"input", 1', '"cloudOutput", 10', '"normalsOutput", 10', '"eigenBasisOutput", 10', '"centerAxisOutput", 10',
+              "displayCylinder", "geometric_mapping_node",
               "boxFilterBound", "voxelGridLeafSize", "neighborRadius", "weightingFactor", "displayCloud", "displayNormals",
               "displayCenterAxis", "usePCLViz"):
         assert s in node, s
