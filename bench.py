@@ -44,8 +44,8 @@ ALGO_BYTES_PER_POINT = 40.0    # SURVEY.md par. 8d: 12 B/pt in + 28 B per croppe
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--radius", type=float, default=None, help="default: fixed-k 0.5*sqrt(50000/points)")
     ap.add_argument("--mode", choices=("frames", "slab"), default="frames")
@@ -230,7 +230,20 @@ def main():
         host_inputs = [ctx._cloud_from_xyz(rows16(f)) for f in frames_host] if mode == "frames" else None
         if host_inputs:
             dt3, _ = timed(ctx, host_inputs, n_slots)
-            secondary["host_input_pcie_inclusive"] = {"value": n * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3}
+            secondary["host_input_pcie_inclusive"] = {"value": n * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3,
+                                                      "input": "pageable host rows: staging copy on the calling thread + H2D"}
+            # the same with rows the caller already holds in page-locked memory (gm_host_alloc, GM_CLOUD_PINNED)
+            pinned_inputs = []
+            for f in frames_host:
+                r16 = rows16(f)
+                buf, as_cloud = ctx.pinned_rows(r16.shape[0], 16)
+                buf[:] = r16.reshape(-1).view(np.uint8)
+                pinned_inputs.append(as_cloud())
+            for pc in pinned_inputs:   # a page-locked buffer's first DMA pays a one-time mapping cost: not steady state
+                ctx.process_frame(pc)
+            dt4, _ = timed(ctx, pinned_inputs, n_slots)
+            secondary["host_input_pinned_pcie_inclusive"] = {"value": n * args.steps / dt4, "ms_per_step": dt4 / args.steps * 1e3,
+                                                             "input": "page-locked host rows (GM_CLOUD_PINNED): H2D only"}
 
     # the same kernel with the chip to itself: frames one at a time (this is also what the kernel sees under
     # rocprofv3, whose host-side overhead keeps the frames from overlapping: profiles/README.md)

@@ -34,6 +34,7 @@ GM_CFG_DEFAULT = GM_CFG_VOXEL_GRID
 
 GM_CLOUD_DEVICE = 1 << 0
 GM_CLOUD_BIGENDIAN = 1 << 1
+GM_CLOUD_PINNED = 1 << 2
 
 GM_RES_VOXEL_PASSTHROUGH = 1 << 0
 
@@ -120,6 +121,8 @@ def load():
         "gm_create": (C.c_int, [cfgp, C.POINTER(vp)]),
         "gm_destroy": (None, [vp]),
         "gm_default_config": (None, [cfgp]),
+        "gm_host_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+        "gm_host_free": (C.c_int, [vp, vp]),
         "gm_abi_version": (u32, []),
         "gm_status_string": (C.c_char_p, [C.c_int]),
         "gm_last_error": (C.c_char_p, [vp]),

@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (GM_CFG_DEFAULT, GM_CFG_KEEP_COUNTS, GM_CFG_STAGE_TIMING, GM_CFG_VOXEL_GRID, GM_CLOUD_BIGENDIAN,
-                   GM_CLOUD_DEVICE, GM_ERR_CAPACITY, GM_OK, Cloud, Config, FrameResult, GmError, STAGE_NAMES)
+                   GM_CLOUD_DEVICE, GM_CLOUD_PINNED, GM_ERR_CAPACITY, GM_OK, Cloud, Config, FrameResult, GmError, STAGE_NAMES)
 
 __all__ = ["GeometricMapping", "GmError", "solve_local_frame", "decode_compressed_map"]
 
@@ -49,6 +49,7 @@ class GeometricMapping:
         cfg.ransac_seed = ransac_seed
         self.cfg = cfg
         self._ctx = C.c_void_p()
+        self._pinned = []
         st = self._L.gm_create(C.byref(cfg), C.byref(self._ctx))
         if st != GM_OK:
             msg = self._L.gm_last_error(None).decode()
@@ -59,6 +60,9 @@ class GeometricMapping:
     # ---- lifetime ----
     def close(self):
         if getattr(self, "_ctx", None):
+            for p in getattr(self, "_pinned", []):
+                self._L.gm_host_free(self._ctx, p)
+            self._pinned = []
             self._L.gm_destroy(self._ctx)
             self._ctx = None
 
@@ -102,6 +106,20 @@ class GeometricMapping:
     def cloud_from_device(ptr, n_points, point_step=16, offsets=(0, 4, 8)):
         """Rows already resident in this device's HBM (e.g. a torch tensor's data_ptr())."""
         return Cloud(int(ptr), n_points, point_step, offsets[0], offsets[1], offsets[2], GM_CLOUD_DEVICE), None
+
+    def pinned_rows(self, n_points, point_step=12):
+        """A page-locked row buffer (numpy uint8 view of gm_host_alloc memory) and a function that wraps it as a
+        GM_CLOUD_PINNED cloud: frames submitted from it skip the staging copy.  Freed with the context."""
+        ptr = C.c_void_p()
+        nbytes = int(n_points) * int(point_step)
+        self._check(self._L.gm_host_alloc(self._ctx, nbytes, C.byref(ptr)))
+        self._pinned.append(ptr)
+        buf = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(max(nbytes, 1),))[:nbytes]
+
+        def as_cloud(n=n_points, offsets=(0, 4, 8), bigendian=False):
+            return Cloud(ptr.value, int(n), int(point_step), offsets[0], offsets[1], offsets[2],
+                         GM_CLOUD_PINNED | (GM_CLOUD_BIGENDIAN if bigendian else 0)), buf
+        return buf, as_cloud
 
     def _as_cloud(self, cloud):
         if isinstance(cloud, tuple) and isinstance(cloud[0], Cloud):

@@ -214,8 +214,12 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud)
     record(ctx, sl, 0);
     const uint8_t *dev_rows = (const uint8_t *)cloud->data;
     if (!on_dev && n) {
-        memcpy(sl.h_raw, cloud->data, raw_bytes);  // pinned staging: the caller's buffer is free again on return
-        GM_HIP(ctx, hipMemcpyAsync(sl.d_raw, sl.h_raw, raw_bytes, hipMemcpyHostToDevice, s));
+        const void *src = cloud->data;
+        if (!(cloud->flags & GM_CLOUD_PINNED)) {
+            memcpy(sl.h_raw, cloud->data, raw_bytes);  // pinned staging: the caller's buffer is free again on return
+            src = sl.h_raw;
+        }
+        GM_HIP(ctx, hipMemcpyAsync(sl.d_raw, src, raw_bytes, hipMemcpyHostToDevice, s));
         dev_rows = sl.d_raw;
     }
     record(ctx, sl, 1);
@@ -438,6 +442,25 @@ gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap)
 }  // namespace gm
 
 extern "C" {
+
+gm_status gm_host_alloc(gm_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out) return fail(ctx, GM_ERR_INVALID_ARG, "gm_host_alloc: NULL argument");
+    *out = nullptr;
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return fail(ctx, GM_ERR_DEVICE, "hipSetDevice failed");
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        *out = nullptr;
+        return fail(ctx, GM_ERR_OOM, "gm_host_alloc: hipHostMalloc failed");
+    }
+    return GM_OK;
+}
+
+gm_status gm_host_free(gm_ctx *ctx, void *ptr)
+{
+    if (!ptr) return GM_OK;
+    if (hipHostFree(ptr) != hipSuccess) return fail(ctx, GM_ERR_INVALID_ARG, "gm_host_free: not a gm_host_alloc pointer");
+    return GM_OK;
+}
 
 uint32_t gm_abi_version(void) { return GM_ABI_VERSION; }
 
@@ -664,8 +687,12 @@ gm_status gm_chop_cloud(gm_ctx *ctx, const gm_cloud *cloud, double bound, float 
     if (st != GM_OK) return st;
     const uint8_t *dev_rows = (const uint8_t *)cloud->data;
     if (!on_dev && n) {
-        memcpy(sl.h_raw, cloud->data, raw_bytes);
-        GM_HIP(ctx, hipMemcpyAsync(sl.d_raw, sl.h_raw, raw_bytes, hipMemcpyHostToDevice, sl.stream));
+        const void *src = cloud->data;
+        if (!(cloud->flags & GM_CLOUD_PINNED)) {
+            memcpy(sl.h_raw, cloud->data, raw_bytes);
+            src = sl.h_raw;
+        }
+        GM_HIP(ctx, hipMemcpyAsync(sl.d_raw, src, raw_bytes, hipMemcpyHostToDevice, sl.stream));
         dev_rows = sl.d_raw;
     }
     RowLayout rows;

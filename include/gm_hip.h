@@ -74,6 +74,9 @@ typedef struct gm_config {
 /* gm_cloud.flags */
 #define GM_CLOUD_DEVICE    (1u << 0) /* data is a device pointer valid on the context's device */
 #define GM_CLOUD_BIGENDIAN (1u << 1) /* sensor_msgs/PointCloud2.is_bigendian */
+#define GM_CLOUD_PINNED    (1u << 2) /* data is page-locked host memory from gm_host_alloc: it is copied to the device
+                                        straight from there (no staging copy on the calling thread) and must stay
+                                        untouched until gm_wait_frame / the blocking call returns */
 
 /* One sensor_msgs/PointCloud2 worth of rows: what pcl::fromROSMsg reads at
  * src/geometric_mapping.cpp:55.  x,y,z are float32 at byte offsets off_* of
@@ -119,6 +122,11 @@ typedef struct gm_frame_result {
  * device, creates one stream + pinned staging + device buffers per slot. */
 gm_status gm_create(const gm_config *cfg, gm_ctx **out);
 void gm_destroy(gm_ctx *ctx);
+
+/* Page-locked host memory for GM_CLOUD_PINNED input (e.g. the buffer a driver or a custom ROS allocator fills with
+ * PointCloud2 rows).  Owned by the caller until gm_host_free; outlives nothing: free it before gm_destroy. */
+gm_status gm_host_alloc(gm_ctx *ctx, size_t bytes, void **out);
+gm_status gm_host_free(gm_ctx *ctx, void *ptr);
 
 /* Defaults = the launch file's values (launch/mapping.launch:7-10). */
 void gm_default_config(gm_config *cfg);

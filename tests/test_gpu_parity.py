@@ -355,3 +355,26 @@ def test_normals_grid_stride_path_is_bitwise_identical(gm):
             outs.append(dict(np.load(f)))
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+
+
+def test_pinned_host_rows_equal_pageable_rows(gm, oc):
+    """GM_CLOUD_PINNED (rows in gm_host_alloc memory, no staging copy) is the same frame as pageable input, also when
+    the frames are submitted asynchronously from two pinned buffers."""
+    xyz = [synth.tunnel_frame(30000, seed=s, outlier_frac=0.01) for s in (21, 22)]
+    with gm.GeometricMapping(n_slots=2) as c:
+        ref = []
+        for x in xyz:
+            r = c.process_frame(x)
+            ref.append((r["scatter"].copy(), c.normals().copy(), c.cropped_cloud()[0].copy()))
+        clouds = []
+        for x in xyz:
+            buf, as_cloud = c.pinned_rows(len(x), 12)
+            buf[:] = np.ascontiguousarray(x).reshape(-1).view(np.uint8)
+            clouds.append(as_cloud())
+        for s, cl in enumerate(clouds):
+            c.submit_frame(s, cl)
+        for s in range(2):
+            r = c.wait_frame(s)
+            assert np.array_equal(r["scatter"], ref[s][0])
+            assert np.array_equal(c.normals(s), ref[s][1], equal_nan=True)
+            assert np.array_equal(c.cropped_cloud(s)[0], ref[s][2])
