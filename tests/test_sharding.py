@@ -153,3 +153,29 @@ def test_gpu_slabs_reproduce_the_unsharded_frame(gm, n_slabs):
     assert ang(V[:, 0], full["center_axis"]) < 1e-5
     mv, mcnt = sharding.merge_voxels(vox, LEAF)
     assert np.array_equal(mcnt, fcnt) and np.abs(mv - fcen).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["frames", "slab"])
+def test_bench_two_rank_rehearsal_on_one_gpu(mode):
+    """The N > 1 path of bench.py exactly as the driver launches it (one process per rank under
+    torch.distributed.run), rehearsed on a one-GPU box: both ranks share device 0 and the collective runs over gloo.
+    Checks the contract fields, not the rate."""
+    import json, subprocess, sys, socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--points", "100000", "--mode", mode, "--dist-backend", "gloo", "--force-device", "0", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["value"] > 0 and d["unit"] == "points/s"
+    assert d["scaling"] == ("weak" if mode == "frames" else "strong") and d["vs_baseline"] is None
+    assert d["config"]["mode"] == mode and d["roofline"]["bound"] == "hbm" and "cpu_baseline" not in d
