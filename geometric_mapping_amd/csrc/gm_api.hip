@@ -386,7 +386,7 @@ gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H)
     const uint32_t HH = H > sl.ext_H ? H : sl.ext_H;
     GM_HIP(ctx, dmalloc(sl.hyp_plane, (size_t)HH * 8)); GM_HIP(ctx, dmalloc(sl.hyp_cyl, (size_t)HH * 8));
     GM_HIP(ctx, dmalloc(sl.band, HH));
-    GM_HIP(ctx, dmalloc(sl.score_partial, (size_t)256));  // pre-selection scratch: sel[64] + counts_k[64]
+    GM_HIP(ctx, dmalloc(sl.score_partial, (size_t)1024));  // pre-selection scratch (k_ransac.hip kPreScratchWords = 576)
     GM_HIP(ctx, dmalloc(sl.cnt_plane, HH)); GM_HIP(ctx, dmalloc(sl.cnt_cyl, HH));
     GM_HIP(ctx, dmalloc(sl.best_plane, 2)); GM_HIP(ctx, dmalloc(sl.best_cyl, 2));
     GM_HIP(ctx, dmalloc(sl.mom_partial, (size_t)kScatterBlocks * 16));
@@ -414,22 +414,22 @@ gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap)
     if (do_plane) {
         uint8_t *lab = first ? nullptr : sl.labels;
         launch_plane_hypotheses(sl.valid4, lab, 0, n_ptr, n_cap, cf.ransac_seed, H, sl.hyp_plane, sl.cnt_plane, s);
-        const bool from_sel = launch_score_preemptive(0, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_plane, sl.band, H,
-                                                      cf.ransac_threshold, sl.score_partial, sl.cnt_plane, sl.best_plane,
-                                                      true, s);
+        const uint32_t *fsel = nullptr; const int32_t *fcnt = nullptr; uint32_t fk = 0;
+        launch_score_preemptive(0, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_plane, sl.band, H, cf.ransac_threshold,
+                                sl.score_partial, sl.cnt_plane, sl.best_plane, true, &fsel, &fcnt, &fk, s);
         launch_label(0, sl.valid4, sl.labels, 0, 1, n_ptr, n_cap, sl.hyp_plane, sl.band, sl.best_plane,
-                     cf.ransac_threshold, first ? 1 : 0, from_sel ? sl.score_partial : nullptr, s);
+                     cf.ransac_threshold, first ? 1 : 0, fsel, fcnt, fk, s);
         first = false;
     }
     if (do_cyl) {
         uint8_t *lab = first ? nullptr : sl.labels;
         launch_cylinder_hypotheses(sl.valid4, sl.vnorm4, lab, 0, n_ptr, n_cap, cf.ransac_seed + 1, H, sl.hyp_cyl,
                                    sl.cnt_cyl, sl.band, cf.ransac_threshold, s);
-        const bool from_sel = launch_score_preemptive(1, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_cyl, sl.band, H,
-                                                      cf.ransac_threshold, sl.score_partial, sl.cnt_cyl, sl.best_cyl,
-                                                      true, s);
+        const uint32_t *fsel = nullptr; const int32_t *fcnt = nullptr; uint32_t fk = 0;
+        launch_score_preemptive(1, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_cyl, sl.band, H, cf.ransac_threshold,
+                                sl.score_partial, sl.cnt_cyl, sl.best_cyl, true, &fsel, &fcnt, &fk, s);
         launch_label(1, sl.valid4, sl.labels, 0, 2, n_ptr, n_cap, sl.hyp_cyl, sl.band, sl.best_cyl,
-                     cf.ransac_threshold, first ? 1 : 0, from_sel ? sl.score_partial : nullptr, s);
+                     cf.ransac_threshold, first ? 1 : 0, fsel, fcnt, fk, s);
         first = false;
     }
     // one pass over the labelled cloud for the moments of both segments; its partials are reduced by the finalizer

@@ -292,46 +292,61 @@ __global__ __launch_bounds__(1024) void k_best_hypothesis(const int32_t *__restr
     if (threadIdx.x == 0) { best[0] = bi[0]; best[1] = bc[0]; }
 }
 
-// ---- pre-selection: keep the K best hypotheses of the sub-sampled scores (count desc, index asc) ----
-constexpr int kPreStride = 8;   // stage 1 scores every 8th point
-constexpr int kPreKeep = 64;    // stage 2 re-scores this many hypotheses on every point
+// ---- preemptive scoring (successive thirds): every stage costs about the same number of point-hypothesis tests ----
+//   stage 1: all H hypotheses on every 32nd point            -> the 256 best (count desc, hypothesis index asc)
+//   stage 2: those 256 on every 8th point                     -> the 32 best
+//   stage 3: those 32 on every point                          -> the winner (taken by the label kernel)
+// (H <= 256 starts at stage 2, H <= 32 is scored exhaustively.)
+constexpr int kPre1Stride = 32, kPre1Keep = 256;
+constexpr int kPre2Stride = 8, kPre2Keep = 32;
+// scratch layout (uint32 words): selA[256] cntA[256] selB[32] cntB[32]
+constexpr int kPreSelA = 0, kPreCntA = 256, kPreSelB = 512, kPreCntB = 544;  // 576 words in all (gm_ensure_ext allocates 1024)
 
-__global__ __launch_bounds__(256) void k_select_topk(const int32_t *__restrict__ counts, uint32_t H, uint32_t K,
-                                                     uint32_t *__restrict__ sel, int32_t *__restrict__ counts_k)
+// Top-K of M scored candidates.  Candidate i has count counts[i] and hypothesis index ids ? ids[i] : i; order =
+// count descending, hypothesis index ascending.  sel[rank] = hypothesis index; block 0 also clears counts_out[0..K).
+__global__ __launch_bounds__(256) void k_select_topk(const int32_t *__restrict__ counts, const uint32_t *__restrict__ ids,
+                                                     uint32_t M, uint32_t K, uint32_t *__restrict__ sel,
+                                                     int32_t *__restrict__ counts_out)
 {
-    // 16 hypotheses per block, 16 lanes per hypothesis: every lane ranks its hypothesis against 1/16 of the
-    // counts (staged in LDS), a 4-step shuffle sum joins the partial ranks
-    extern __shared__ int32_t lc[];  // [H]
-    for (uint32_t h = threadIdx.x; h < H; h += 256) lc[h] = counts[h];
-    if (blockIdx.x == 0 && threadIdx.x < K) counts_k[threadIdx.x] = 0;  // stage-2 counters start at zero
+    // 16 candidates per block, 16 lanes per candidate: every lane ranks its candidate against 1/16 of the
+    // list (staged in LDS), a 4-step shuffle sum joins the partial ranks
+    extern __shared__ int32_t lc[];  // [M] counts, then [M] hypothesis indices
+    uint32_t *li = reinterpret_cast<uint32_t *>(lc + M);
+    for (uint32_t i = threadIdx.x; i < M; i += 256) { lc[i] = counts[i]; li[i] = ids ? ids[i] : i; }
+    if (blockIdx.x == 0)
+        for (uint32_t k = threadIdx.x; k < K; k += 256) counts_out[k] = 0;  // the next stage's counters start at zero
     __syncthreads();
-    const uint32_t h = blockIdx.x * 16u + threadIdx.x / 16u, part = threadIdx.x & 15u;
-    const int32_t c = h < H ? lc[h] : 0;
+    const uint32_t i = blockIdx.x * 16u + threadIdx.x / 16u, part = threadIdx.x & 15u;
+    const int32_t c = i < M ? lc[i] : 0;
+    const uint32_t h = i < M ? li[i] : 0xFFFFFFFFu;
     uint32_t rank = 0;
-    for (uint32_t o = part; o < H; o += 16u) {
+    for (uint32_t o = part; o < M; o += 16u) {
         const int32_t co = lc[o];
-        rank += (co > c || (co == c && o < h)) ? 1u : 0u;
+        rank += (co > c || (co == c && li[o] < h)) ? 1u : 0u;
     }
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) rank += __shfl_xor(rank, o, kWave);
-    if (h < H && part == 0 && rank < K) sel[rank] = h;  // ranks are a permutation: slots < min(K,H) are written once
+    if (i < M && part == 0 && rank < K) sel[rank] = h;  // ranks are a permutation: slots < min(K,M) are written once
 }
 
-// Stage 2: the K <= 64 selected hypotheses against every point.  Same shape as k_score: lane <-> selected
-// hypothesis (in registers), each of the block's 4 waves owns 256 points staged in LDS as SoA groups of four,
-// pure-VALU inner loop, LDS reduce over the waves, one integer atomicAdd per (block, hypothesis).
+// Later stages: K selected hypotheses against every stride-th point.  Same shape as k_score: lane <-> selected
+// hypothesis (in registers; blockIdx.y picks the chunk of 64), each of the block's 4 waves owns 256 points staged
+// in LDS as SoA groups of four, pure-VALU inner loop, LDS reduce over the waves, one integer atomicAdd per
+// (block, hypothesis).
 template <int MODEL>
 __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pts, const uint8_t *__restrict__ labels,
                                                    uint32_t want, const uint32_t *__restrict__ n_ptr, uint32_t n_host,
                                                    const float *__restrict__ hyp8, const float2 *__restrict__ band,
                                                    const uint32_t *__restrict__ sel, uint32_t K, float tau,
-                                                   int32_t *__restrict__ counts_k)
+                                                   uint32_t stride, int32_t *__restrict__ counts_k)
 {
     constexpr int PTS = 256;  // per wave
     __shared__ float4 lp[4][PTS / 4][3];
     __shared__ float red[4][64];
-    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    const uint32_t n_full = n_ptr ? *n_ptr : n_host;
+    const uint32_t n = (n_full + stride - 1) / stride;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t slot = blockIdx.y * 64u + lane;  // which selected hypothesis this lane scores
     const uint32_t base = (blockIdx.x * 4u + wave) * PTS;
     const uint32_t m = base >= n ? 0u : ((n - base < (uint32_t)PTS) ? n - base : (uint32_t)PTS);
     const uint32_t groups = (m + 3u) >> 2;
@@ -339,8 +354,8 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
 #pragma unroll
     for (int p = 0; p < PTS / 64; ++p) {
         const uint32_t j = p * 64 + lane;
-        const uint32_t i = base + j;
-        bool ok = i < n;
+        const uint32_t i = (base + j) * stride;
+        bool ok = base + j < n;
         if (ok && labels) ok = labels[i] == want;
         float4 v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 0.f);
         if (ok) v = pts[i];  // masked / out-of-range points are NaN: never an inlier
@@ -348,8 +363,8 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
         gp[(j & 3)] = v.x; gp[4 + (j & 3)] = v.y; gp[8 + (j & 3)] = v.z;
     }
     float h0 = __builtin_nanf(""), h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, lo2 = 0, hi2 = 0;
-    if (lane < K) {
-        const uint32_t h = sel[lane];
+    if (slot < K) {
+        const uint32_t h = sel[slot];
         const float4 a = *reinterpret_cast<const float4 *>(hyp8 + 8 * (size_t)h);
         h0 = a.x; h1 = a.y; h2 = a.z; h3 = a.w;
         if (MODEL == 1) {
@@ -371,9 +386,9 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
     }
     red[wave][lane] = c;
     __syncthreads();
-    if (wave == 0 && lane < K) {
+    if (wave == 0 && slot < K) {
         const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];  // exact: integers <= 1024
-        if (t > 0.f) atomicAdd(&counts_k[lane], (int32_t)t);
+        if (t > 0.f) atomicAdd(&counts_k[slot], (int32_t)t);
     }
 }
 
@@ -637,55 +652,78 @@ void launch_score(int model, const float4 *pts, const uint8_t *labels, uint32_t 
     hipLaunchKernelGGL(k_best_hypothesis, dim3(1), dim3(1024), 0, s, (const int32_t *)counts, H, best);
 }
 
-// In-frame RANSAC: preemptive scoring.  Stage 1 scores all H hypotheses on every kPreStride-th point,
-// stage 2 re-scores the kPreKeep best of them on every point; the winner is the best full count.
-// `scratch` holds sel[kPreKeep] followed by counts_k[kPreKeep].
+// In-frame RANSAC: preemptive scoring in three stages of equal cost (see kPre* above).  `scratch` holds
+// kPreScratchWords words.  Returns false when H was small enough for the exhaustive scorer (the winner is then in
+// `best`); otherwise the winner is still to be taken from (*sel_out, *cnt_out, *k_out) -- the label kernel does that.
+// prepared: the hypothesis kernel already cleared `counts` and wrote the cylinder bands.
+template <int MODEL>
+static void score_stage_all(const float4 *pts, const uint8_t *labels, uint32_t want, const uint32_t *n_ptr, uint32_t n_cap,
+                            const float *hyp8, const float2 *band, uint32_t H, double tau, uint32_t stride,
+                            int32_t *counts, hipStream_t s)
+{
+    const uint32_t n_sub = (n_cap + stride - 1) / stride;
+    const uint32_t nb = score_blocks(n_sub) ? score_blocks(n_sub) : 1;
+    hipLaunchKernelGGL(k_score<MODEL>, dim3(nb, (H + kScHC - 1) / kScHC), dim3(kScThreads), 0, s, pts, labels, want, n_ptr,
+                       n_cap, hyp8, band, H, (float)tau, stride, counts);
+}
+template <int MODEL>
+static void score_stage_sel(const float4 *pts, const uint8_t *labels, uint32_t want, const uint32_t *n_ptr, uint32_t n_cap,
+                            const float *hyp8, const float2 *band, const uint32_t *sel, uint32_t K, double tau,
+                            uint32_t stride, int32_t *counts_k, hipStream_t s)
+{
+    const uint32_t n_sub = (n_cap + stride - 1) / stride;
+    const uint32_t nb = (n_sub + 1023) / 1024 ? (n_sub + 1023) / 1024 : 1;
+    hipLaunchKernelGGL(k_score_sel<MODEL>, dim3(nb, (K + 63) / 64), dim3(256), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
+                       band, sel, K, (float)tau, stride, counts_k);
+}
+static void select_topk(const int32_t *counts, const uint32_t *ids, uint32_t M, uint32_t K, uint32_t *sel,
+                        int32_t *counts_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_select_topk, dim3((M + 15) / 16), dim3(256), 2 * sizeof(int32_t) * M, s, counts, ids, M, K, sel,
+                       counts_out);
+}
+
 bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels, uint32_t want,
                              const uint32_t *n_ptr, uint32_t n_cap, const float *hyp8, float2 *band, uint32_t H,
                              double tau, uint32_t *scratch, int32_t *counts, uint32_t *best, bool prepared,
-                             hipStream_t s)
+                             const uint32_t **sel_out, const int32_t **cnt_out, uint32_t *k_out, hipStream_t s)
 {
-    // prepared: the hypothesis kernel already cleared `counts` and wrote the cylinder bands.  Returns true when
-    // the winner is still to be taken from scratch (sel[K], counts_k[K]) -- the label kernel does that.
-    if (H <= (uint32_t)kPreKeep) {  // nothing to pre-select
+    if (H <= (uint32_t)kPre2Keep) {  // nothing to pre-select
         launch_score(model, pts, labels, want, n_ptr, n_cap, hyp8, band, H, tau, nullptr, counts, best, s);
         return false;
     }
-    const uint32_t n_sub = (n_cap + kPreStride - 1) / kPreStride;
-    const uint32_t nb = score_blocks(n_sub) ? score_blocks(n_sub) : 1;
-    const dim3 grid(nb, (H + kScHC - 1) / kScHC);
-    uint32_t *sel = scratch;
-    int32_t *counts_k = (int32_t *)(scratch + kPreKeep);
+    uint32_t *selA = scratch + kPreSelA, *selB = scratch + kPreSelB;
+    int32_t *cntA = (int32_t *)(scratch + kPreCntA), *cntB = (int32_t *)(scratch + kPreCntB);
     if (!prepared) {
-        hipMemsetAsync(counts, 0, sizeof(int32_t) * H, s);  // (counts_k is zeroed by k_select_topk)
+        hipMemsetAsync(counts, 0, sizeof(int32_t) * H, s);
         if (model == 1) hipLaunchKernelGGL(k_cyl_bands, dim3((H + 255) / 256), dim3(256), 0, s, hyp8, H, tau, band);
     }
-    const uint32_t K = kPreKeep;
-    const uint32_t nbf = (n_cap + 1023) / 1024 ? (n_cap + 1023) / 1024 : 1;
-    if (model == 0) {
-        hipLaunchKernelGGL(k_score<0>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
-                           (const float2 *)band, H, (float)tau, (uint32_t)kPreStride, counts);
-        hipLaunchKernelGGL(k_select_topk, dim3((H + 15) / 16), dim3(256), sizeof(int32_t) * H, s, (const int32_t *)counts, H, K, sel, counts_k);
-        hipLaunchKernelGGL(k_score_sel<0>, dim3(nbf), dim3(256), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
-                           (const float2 *)band, (const uint32_t *)sel, K, (float)tau, counts_k);
+    const float2 *cb = band;
+    const uint32_t K2 = kPre2Keep;
+    if (H > (uint32_t)kPre1Keep) {
+        const uint32_t K1 = kPre1Keep;
+        if (model == 0) score_stage_all<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre1Stride, counts, s);
+        else score_stage_all<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre1Stride, counts, s);
+        select_topk(counts, nullptr, H, K1, selA, cntA, s);
+        if (model == 0) score_stage_sel<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selA, K1, tau, kPre2Stride, cntA, s);
+        else score_stage_sel<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selA, K1, tau, kPre2Stride, cntA, s);
+        select_topk(cntA, selA, K1, K2, selB, cntB, s);
     } else {
-        hipLaunchKernelGGL(k_score<1>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
-                           (const float2 *)band, H, (float)tau, (uint32_t)kPreStride, counts);
-        hipLaunchKernelGGL(k_select_topk, dim3((H + 15) / 16), dim3(256), sizeof(int32_t) * H, s, (const int32_t *)counts, H, K, sel, counts_k);
-        hipLaunchKernelGGL(k_score_sel<1>, dim3(nbf), dim3(256), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
-                           (const float2 *)band, (const uint32_t *)sel, K, (float)tau, counts_k);
+        if (model == 0) score_stage_all<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre2Stride, counts, s);
+        else score_stage_all<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre2Stride, counts, s);
+        select_topk(counts, nullptr, H, K2, selB, cntB, s);
     }
+    if (model == 0) score_stage_sel<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selB, K2, tau, 1u, cntB, s);
+    else score_stage_sel<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selB, K2, tau, 1u, cntB, s);
+    *sel_out = selB; *cnt_out = cntB; *k_out = K2;
     return true;
 }
 
 void launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, uint32_t label, const uint32_t *n_ptr,
                   uint32_t n_cap, const float *hyp8, const float2 *band, uint32_t *best, double tau, int init,
-                  const uint32_t *sel_scratch, hipStream_t s)
+                  const uint32_t *sel, const int32_t *counts_k, uint32_t K, hipStream_t s)
 {
-    // sel_scratch != nullptr: winner = best of the kPreKeep re-scored hypotheses in (sel[K], counts_k[K])
-    const uint32_t *sel = sel_scratch;
-    const int32_t *counts_k = sel_scratch ? (const int32_t *)(sel_scratch + kPreKeep) : nullptr;
-    const uint32_t K = kPreKeep;
+    // counts_k != nullptr: winner = best of the K (<= 64) finally re-scored hypotheses in (sel[K], counts_k[K])
     uint32_t nb = (n_cap + 255) / 256;
     if (nb > 2048) nb = 2048;
     if (nb == 0) nb = 1;

@@ -100,19 +100,19 @@ def test_nearest(ctx, oc):
     assert ctx.nearest(xyz[:1], cen).tolist() == [0] * len(cen)
 
 
-def preemptive_best(score_fn, cloud, hyp, labels, want=0, stride=8, keep=64):
-    """The in-frame RANSAC's two-stage scoring (csrc/k_ransac.hip launch_score_preemptive), restated with the
-    oracle's exhaustive scorer: all hypotheses on every 8th point -> 64 best (count desc, index asc) -> those on
-    every point -> best full count (lowest index on ties)."""
-    if len(hyp) <= keep:
-        c = score_fn(cloud, hyp, TAU, labels, want)
-        k = np.lexsort((np.arange(len(hyp)), -c))[0]
-        return int(k), int(c[k])
-    c1 = score_fn(cloud[::stride], hyp, TAU, labels[::stride], want)
-    sel = np.lexsort((np.arange(len(hyp)), -c1))[:keep]
-    c2 = score_fn(cloud, hyp[sel], TAU, labels, want)
-    k = np.lexsort((sel, -c2))[0]
-    return int(sel[k]), int(c2[k])
+def preemptive_best(score_fn, cloud, hyp, labels, want=0):
+    """The in-frame RANSAC's staged scoring (csrc/k_ransac.hip launch_score_preemptive), restated with the oracle's
+    exhaustive scorer: all hypotheses on every 32nd point -> 256 best (count desc, index asc) -> those on every
+    8th point -> 32 best -> those on every point -> best full count (lowest index on ties).  H <= 256 starts at the
+    second stage, H <= 32 is exhaustive."""
+    ids = np.arange(len(hyp))
+    for stride, keep in ((32, 256), (8, 32)):
+        if len(ids) > keep:
+            c = score_fn(cloud[::stride], hyp[ids], TAU, labels[::stride], want)
+            ids = ids[np.lexsort((ids, -c))[:keep]]
+    c = score_fn(cloud, hyp[ids], TAU, labels, want)
+    k = np.lexsort((ids, -c))[0]
+    return int(ids[k]), int(c[k])
 
 
 def test_frame_ransac_plane_then_cylinder(gm, oc):
