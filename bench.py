@@ -149,9 +149,12 @@ def main():
         n_slots = 1
     torch.cuda.synchronize()
 
+    tau_r = 0.03  # RANSAC inlier threshold (3 sigma of the generator), H = 1024 hypotheses per model
+
     def make_ctx(fl, slots):
         c = g.GeometricMapping(boxFilterBound=bound, voxelGridLeafSize=leaf, neighborRadius=radius, weightingFactor=wf,
-                               device=local_rank, flags=fl, n_slots=slots, max_points=max(len(d) for d in dev))
+                               device=local_rank, flags=fl, n_slots=slots, max_points=max(len(d) for d in dev),
+                               ransac_hypotheses=1024, ransac_threshold=tau_r, ransac_seed=1 + rank)
         if own is not None:
             c.set_owned_range(*own)
         return c
@@ -167,12 +170,29 @@ def main():
     rec_dev = torch.zeros(sharding.RECORD_LEN, dtype=torch.float64, device=coll_dev)
     gathered = torch.zeros(world * sharding.RECORD_LEN, dtype=torch.float64, device=coll_dev)
 
+    prim_dev = torch.zeros(sharding.PRIMITIVE_LEN, dtype=torch.float64, device=coll_dev)
+    prim_all = torch.zeros(world * sharding.PRIMITIVE_LEN, dtype=torch.float64, device=coll_dev)
+    votes_dev = torch.zeros(2 * world, dtype=torch.int64, device=coll_dev)
+
     def slab_step(c):
         res = c.process_frame(clouds[0])
         rec_dev.copy_(torch.from_numpy(sharding.pack_record(res)))
         dist.all_gather_into_tensor(gathered, rec_dev)
         sc, _ = sharding.unpack_records(gathered.cpu().numpy())
         g.solve_local_frame(sharding.merge_scatter(sc))
+        if ransac_on:
+            # primitive vote (sharding.py): all-gather of every rank's fitted primitives, each rank counts every
+            # candidate on its own resident slab, all-reduce of the counts, largest global count wins
+            prim_dev.copy_(torch.from_numpy(sharding.pack_primitives(res)))
+            dist.all_gather_into_tensor(prim_all, prim_dev)
+            planes, cyls, _ = sharding.unpack_primitives(prim_all.cpu().numpy())
+            v = np.zeros(2 * world, dtype=np.int64)
+            ok = np.isfinite(cyls).all(axis=1)
+            if ok.any():
+                v[world:][ok] = c.score_frame(1, cyls[ok], tau_r)
+            votes_dev.copy_(torch.from_numpy(v))
+            dist.all_reduce(votes_dev, op=dist.ReduceOp.SUM)
+            res["cylinder_voted"] = sharding.vote_primitives(cyls, votes_dev.cpu().numpy()[world:])
         return res
 
     def run(c, inputs, steps, slots, results):

@@ -143,6 +143,7 @@ def load():
         "gm_solve_local_frame": (C.c_int, [dp, fp, fp]),
         "gm_set_owned_range": (C.c_int, [vp, C.c_double, C.c_double]),
         "gm_ext_available": (C.c_int, []),
+        "gm_score_frame": (C.c_int, [vp, u32, C.c_int, fp, u32, C.c_double, u32, i32p]),
         "gm_score_planes": (C.c_int, [vp, fp, u32, u8p, u32, fp, u32, C.c_double, i32p]),
         "gm_score_cylinders": (C.c_int, [vp, fp, u32, u8p, u32, fp, u32, C.c_double, i32p]),
         "gm_plane_hypotheses": (C.c_int, [vp, fp, u32, u8p, u32, C.c_uint64, u32, fp]),

@@ -309,6 +309,17 @@ class GeometricMapping:
     def score_cylinders(self, cloud, hyp7, tau, labels=None, want=0):
         return self._score(self._L.gm_score_cylinders, cloud, hyp7, tau, labels, want)
 
+    def score_frame(self, model, hyp, tau, slot=0, unlabelled_only=False):
+        """Inlier counts of caller-supplied hypotheses ([H,4] plane rows if model == 0, [H,7] cylinder rows if 1) on the
+        valid cloud the last frame left in `slot` (owned points only when sharded): gm_score_frame."""
+        w = 4 if model == 0 else 7
+        hyp = np.ascontiguousarray(np.asarray(hyp, dtype=np.float32).reshape(-1, w))
+        counts = np.zeros(max(len(hyp), 1), dtype=np.int32)
+        if len(hyp):
+            self._check(self._L.gm_score_frame(self._ctx, slot, int(model), _f32(hyp), len(hyp), float(tau),
+                                               1 if unlabelled_only else 0, counts.ctypes.data_as(C.POINTER(C.c_int32))))
+        return counts[:len(hyp)]
+
     def segment_moments(self, cloud, normals, labels, label):
         xyz = np.ascontiguousarray(cloud, dtype=np.float32)
         nrm = np.ascontiguousarray(normals, dtype=np.float32) if normals is not None else None

@@ -4,6 +4,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <vector>
+
 #include "gm_internal.hpp"
 
 using namespace gm;
@@ -95,6 +97,34 @@ gm_status gm_score_cylinders(gm_ctx *ctx, const float *xyz, uint32_t n, const ui
                              const float *hyp7, uint32_t H, double tau, int32_t *counts)
 {
     return score(ctx, 1, xyz, n, labels, want, hyp7, H, tau, counts);
+}
+
+gm_status gm_score_frame(gm_ctx *ctx, uint32_t slot, int model, const float *hyp, uint32_t H, double tau,
+                         uint32_t unlabelled_only, int32_t *counts)
+{
+    gm_status st = gm_check_slot(ctx, slot);
+    if (st != GM_OK) return st;
+    if (!hyp || !counts || (model != 0 && model != 1)) return gm_fail(ctx, GM_ERR_INVALID_ARG, "gm_score_frame: bad argument");
+    if (unlabelled_only && !(ctx->cfg.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)))
+        return gm_fail(ctx, GM_ERR_NOT_READY, "unlabelled_only needs a context created with a GM_CFG_RANSAC_* flag");
+    Slot &sl = ctx->slots[slot];
+    st = gm_ensure_ext(ctx, sl, H);
+    if (st != GM_OK) return st;
+    // caller rows (4 or 7 floats) -> internal rows of 8
+    const int w = model == 0 ? 4 : 7;
+    std::vector<float> rows((size_t)H * 8, 0.f);
+    for (uint32_t h = 0; h < H; ++h)
+        for (int k = 0; k < w; ++k) rows[8 * (size_t)h + k] = hyp[(size_t)w * h + k];
+    float *dh = model == 0 ? sl.hyp_plane : sl.hyp_cyl;
+    GMX_HIP(ctx, hipMemcpyAsync(dh, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, sl.stream));
+    GMX_HIP(ctx, hipStreamSynchronize(sl.stream));  // `rows` is pageable and about to go away
+    // exhaustive scorer over the slot's resident valid cloud (owned points only: halo rows never reach it)
+    launch_score(model, sl.valid4, unlabelled_only ? sl.labels : nullptr, 0, &sl.ctr->n_valid, sl.last.n_valid, dh, sl.band,
+                 H, tau, nullptr, sl.cnt_plane, sl.score_partial + 600, sl.stream);
+    GMX_HIP(ctx, hipMemcpyAsync(counts, sl.cnt_plane, (size_t)H * 4, hipMemcpyDeviceToHost, sl.stream));
+    GMX_HIP(ctx, hipStreamSynchronize(sl.stream));
+    GMX_HIP(ctx, hipGetLastError());
+    return GM_OK;
 }
 
 gm_status gm_plane_hypotheses(gm_ctx *ctx, const float *xyz, uint32_t n, const uint8_t *labels, uint32_t want,

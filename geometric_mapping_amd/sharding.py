@@ -17,7 +17,7 @@ from __future__ import annotations
 import numpy as np
 
 __all__ = ["slab_edges", "cut_slabs", "merge_scatter", "merge_clouds", "merge_voxels", "RECORD_LEN",
-           "pack_record", "unpack_records"]
+           "pack_record", "unpack_records", "PRIMITIVE_LEN", "pack_primitives", "unpack_primitives", "vote_primitives"]
 
 
 def slab_edges(xyz, n_slabs, bound):
@@ -65,6 +65,43 @@ def pack_record(res):
 def unpack_records(recs):
     recs = np.asarray(recs, dtype=np.float64).reshape(-1, RECORD_LEN)
     return recs[:, :6], recs[:, 6:].astype(np.int64)
+
+
+# ---- fitted primitives of a sharded frame (north_star: "all-gather of fitted primitives") -------------------------
+# Every rank fits its own plane / cylinder on its slab (the in-frame RANSAC).  Those fits are CANDIDATES for the
+# whole frame: round 1 all-gathers them (PRIMITIVE_LEN doubles per rank), then every rank counts the inliers of every
+# candidate on its OWN slab (gm_score_frame: owned points only, so counts add up exactly), round 2 sums the counts
+# over the ranks, and the candidate with the largest global count wins (lowest rank on ties).  Two collectives of a
+# few hundred bytes; no point ever crosses a link.
+PRIMITIVE_LEN = 13  # plane a,b,c,d | cylinder px,py,pz,dx,dy,dz,r | plane_inliers, cylinder_inliers (local)
+
+
+def pack_primitives(res):
+    r = np.full(PRIMITIVE_LEN, np.nan, dtype=np.float64)
+    r[0:4] = res["plane"]
+    r[4:11] = res["cylinder"]
+    r[11:13] = [res["plane_inliers"], res["cylinder_inliers"]]
+    return r
+
+
+def unpack_primitives(recs):
+    """-> (planes [world,4] float32, cylinders [world,7] float32, local inlier counts [world,2])."""
+    recs = np.asarray(recs, dtype=np.float64).reshape(-1, PRIMITIVE_LEN)
+    return recs[:, 0:4].astype(np.float32), recs[:, 4:11].astype(np.float32), recs[:, 11:13].astype(np.int64)
+
+
+def vote_primitives(candidates, global_counts):
+    """candidates [world, k] rows, global_counts [world] = inliers of each candidate summed over all slabs.
+    Returns (winning row or None, its count, index): largest count, lowest rank on ties; candidates holding a NaN
+    (a rank whose slab produced no model) never win."""
+    cand = np.asarray(candidates)
+    cnt = np.asarray(global_counts, dtype=np.int64).copy()
+    ok = np.isfinite(cand).all(axis=1)
+    if not ok.any():
+        return None, 0, -1
+    cnt[~ok] = -1
+    k = int(np.argmax(cnt))  # argmax returns the first maximum: lowest rank on ties
+    return cand[k].copy(), int(cnt[k]), k
 
 
 def merge_scatter(scatter6_rows):

@@ -236,6 +236,13 @@ gm_status gm_score_planes(gm_ctx *ctx, const float *xyz, uint32_t n, const uint8
 gm_status gm_score_cylinders(gm_ctx *ctx, const float *xyz, uint32_t n, const uint8_t *labels, uint32_t want,
                              const float *hyp7, uint32_t H, double tau, int32_t *counts);
 /* Seeded minimal-sample hypotheses generated on the device (splitmix64 counter PRNG). */
+/* Score caller-supplied hypotheses against the valid cloud a completed frame left in `slot` (no upload of points).
+ * model 0: plane rows a,b,c,d; 1: cylinder rows px,py,pz,dx,dy,dz,r.  unlabelled_only != 0 counts only points the
+ * frame's own RANSAC left unlabelled.  With gm_set_owned_range the valid cloud holds owned points only, so the counts
+ * of the ranks of a sharded frame add up to the count on the whole frame: the building block of the multi-GPU
+ * primitive vote (geometric_mapping_amd/sharding.py, DESIGN.md par. 6). */
+gm_status gm_score_frame(gm_ctx *ctx, uint32_t slot, int model, const float *hyp, uint32_t H, double tau,
+                         uint32_t unlabelled_only, int32_t *counts);
 gm_status gm_plane_hypotheses(gm_ctx *ctx, const float *xyz, uint32_t n, const uint8_t *labels, uint32_t want,
                               uint64_t seed, uint32_t H, float *hyp4);
 gm_status gm_cylinder_hypotheses(gm_ctx *ctx, const float *xyz, const float *nxyzc, uint32_t n,
