@@ -13,9 +13,11 @@
 //    sort of cell keys, x fastest, so the 3x3x3 neighbourhood of a run of cells
 //    in one x-row is 9 CONTIGUOUS ranges of the sorted array;
 //  * a work item ("tile") is <= 64 consecutive sorted points of one x-row: one
-//    query per lane, the tile's candidates are streamed through a 1 KiB
-//    wave-private LDS window (coalesced 16 B/lane loads in, broadcast
-//    ds_read_b128 out), so no block barrier exists in the hot loop;
+//    query per lane, the tile's candidates are streamed through a 4 KiB
+//    wave-private SoA LDS window (coalesced 16 B/lane loads in, broadcast
+//    ds_read_b128 out: four candidates' x, y or z per read), so no block
+//    barrier exists in the hot loop; the wave's four 16-lane groups walk
+//    their own x-windows of a row in lock-step;
 //  * each lane keeps 10 fp32 accumulators of offsets FROM ITS OWN QUERY POINT
 //    (|offset| < r: no cancellation), folded into fp64 once per 64 candidates;
 //  * the 3x3 solve runs in fp64 (MI355X fp64 vector rate is half the fp32 rate;
@@ -523,7 +525,7 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
                        sl.row_bounds);
     hipLaunchKernelGGL(k_build_tiles, dim3((n_cap + 1023) / 1024), dim3(1024), 0, s, (const uint32_t *)skeys, sl.ctr, (uint32_t)g.nx,
                        (uint32_t)(kTileSpan * (g.xreach - 1)), (const uint2 *)sl.row_bounds, sl.tiles, sl.tiles_cap);
-    // persistent grid: 8 blocks of 4 waves per CU fill every SIMD's 8 wave slots
+    // one wave per tile: four tiles per block
     const uint32_t mt = max_tiles(n_cap, g);
     uint32_t nb = (mt + kNrWaves - 1) / kNrWaves;
     {

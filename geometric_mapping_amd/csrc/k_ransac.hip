@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
 // init != 0: this is the first model of the frame -- every point is eligible and labels are WRITTEN for all
 // points (no memset of the label array is needed); otherwise only points with labels == want are touched.
 // counts_k != nullptr: the winner is taken from the K re-scored hypotheses (largest count, lowest hypothesis index
-// on ties) by every block for itself, and block 0 publishes it in best[0..1] (k_best_of_selected folded in).
+// on ties) by every block for itself, and block 0 publishes it in best[0..1].
 template <int MODEL>
 __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, uint8_t *__restrict__ labels,
                                                uint32_t want, uint32_t label, const uint32_t *__restrict__ n_ptr,
