@@ -65,6 +65,8 @@ struct VoxDense {
     float lo;            // lower face of the crop box
     float own_lo, own_hi;// slab ownership (multi-GPU), +-inf otherwise
     double scale, inv_scale;
+    uint32_t xcd_chunk;  // k_normals launch option riding along: blocks per XCD chunk of the tile mapping (0 = round-robin)
+    uint32_t pad_;
 };
 
 // extension outputs (RANSAC plane / cylinder; no reference counterpart)
