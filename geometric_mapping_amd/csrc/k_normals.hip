@@ -409,13 +409,19 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
             // a group whose window is shorter than the longest one keeps reading: first real candidates of
             // the row beyond its window (they fail the distance test), then the far padding behind the chunk
             const uint32_t lim = (clen + 3u) & ~3u;  // first all-padding group of four
-            auto four = [&](const float4 cx4, const float4 cy4, const float4 cz4) {
+            // offsets of four candidates from this lane's query: after this the candidate registers are dead
+            struct Off4 { v2f dx[2], dy[2], dz[2]; };
+            auto offsets = [&](const float4 cx4, const float4 cy4, const float4 cz4) {
+                Off4 o;
+                o.dx[0] = (v2f){cx4.x, cx4.y} - qx; o.dx[1] = (v2f){cx4.z, cx4.w} - qx;
+                o.dy[0] = (v2f){cy4.x, cy4.y} - qy; o.dy[1] = (v2f){cy4.z, cy4.w} - qy;
+                o.dz[0] = (v2f){cz4.x, cz4.y} - qz; o.dz[1] = (v2f){cz4.z, cz4.w} - qz;
+                return o;
+            };
+            auto accumulate = [&](const Off4 &o) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const v2f cx = h ? (v2f){cx4.z, cx4.w} : (v2f){cx4.x, cx4.y};
-                    const v2f cy2 = h ? (v2f){cy4.z, cy4.w} : (v2f){cy4.x, cy4.y};
-                    const v2f cz2 = h ? (v2f){cz4.z, cz4.w} : (v2f){cz4.x, cz4.y};
-                    const v2f dx = cx - qx, dy = cy2 - qy, dz = cz2 - qz;
+                    const v2f dx = o.dx[h], dy = o.dy[h], dz = o.dz[h];
                     // FLANN L2_Simple: every product and sum rounded, in this order
                     const v2f xx = pk_mul_rn(dx, dx), yy = pk_mul_rn(dy, dy), zz = pk_mul_rn(dz, dz);
                     const v2f d2 = pk_add_rn(pk_add_rn(xx, yy), zz);
@@ -428,18 +434,25 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
                     sxy += mx * dy; sxz += mx * dz; syz += my * dz;
                 }
             };
-            // two groups of four candidates per trip: all six LDS reads are issued before the first group is
-            // consumed, so the second group's latency hides behind the first group's arithmetic
+            // Two groups of four candidates per trip, software-pipelined with NO extra registers: a group's candidate
+            // registers are dead once its six offset subtractions are done, so its LDS reads for the NEXT trip are
+            // re-issued right there and have the rest of the trip (~300 cycles of arithmetic) to land, instead of
+            // stalling the wave at the top of every trip.  (Reads past the window are clamped to `lim`: far-away
+            // padding or real non-neighbours, harmless.)
+            auto rd = [&](const float *base, uint32_t a) { return *reinterpret_cast<const float4 *>(base + (a < lim ? a : lim)); };
+            uint32_t a = ob;
+            float4 x0 = rd(wx, a), y0 = rd(wy, a), z0 = rd(wz, a);
+            float4 x1 = rd(wx, a + 4u), y1 = rd(wy, a + 4u), z1 = rd(wz, a + 4u);
             for (int it = 0; it < iters; it += 2) {
-                uint32_t a0 = ob + 4u * (uint32_t)it, a1 = a0 + 4u;
-                a0 = a0 < lim ? a0 : lim;
-                a1 = a1 < lim ? a1 : lim;   // (an odd trip count reads one extra group: real or far points, harmless)
-                const float4 x0 = *reinterpret_cast<const float4 *>(wx + a0), y0 = *reinterpret_cast<const float4 *>(wy + a0),
-                             z0 = *reinterpret_cast<const float4 *>(wz + a0);
-                const float4 x1 = *reinterpret_cast<const float4 *>(wx + a1), y1 = *reinterpret_cast<const float4 *>(wy + a1),
-                             z1 = *reinterpret_cast<const float4 *>(wz + a1);
-                four(x0, y0, z0);
-                four(x1, y1, z1);
+                a += 8u;
+                const Off4 oa = offsets(x0, y0, z0);
+                x0 = rd(wx, a); y0 = rd(wy, a); z0 = rd(wz, a);
+                __builtin_amdgcn_sched_barrier(0);  // keep the re-issue here
+                accumulate(oa);
+                const Off4 ob4 = offsets(x1, y1, z1);
+                x1 = rd(wx, a + 4u); y1 = rd(wy, a + 4u); z1 = rd(wz, a + 4u);
+                __builtin_amdgcn_sched_barrier(0);
+                accumulate(ob4);
                 since_fold += 2;
                 if (since_fold >= GM_FOLD_TRIPS) fold();  // 16 trips = every 64 candidates (32 per packed half)
             }
