@@ -119,7 +119,27 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__res
         }
     }
     // ---- start of this block's span for every digit: exclusive scan of the digit
-    //      totals + histogram rows of the blocks before this one
+    //      totals + histogram rows of the blocks before this one.  The rows are summed by ALL threads: thread t
+    //      takes column t % BINS and every RG-th row starting at t / BINS (RG = threads / BINS row groups, 8 rows
+    //      in flight each), the row groups are joined through LDS -- the serial chain of the last block is
+    //      blocks / (8 RG) dependent steps instead of blocks / 8.
+    __shared__ uint32_t colsum[kRsThreads];
+    constexpr int RG = BINS < kRsThreads ? kRsThreads / BINS : 1;  // row groups (BINS is a power of two)
+    if (BINS < kRsThreads) {
+        const int col = threadIdx.x % BINS, rg = threadIdx.x / BINS;
+        uint32_t acc = 0;
+        uint32_t b = (uint32_t)rg;
+        for (; b + 7u * RG < blockIdx.x; b += 8u * RG) {
+            uint32_t r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = hist[(size_t)(b + (uint32_t)u * RG) * BINS + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += r[u];
+        }
+        for (; b < blockIdx.x; b += RG) acc += hist[(size_t)b * BINS + col];
+        colsum[threadIdx.x] = acc;
+    }
+    __syncthreads();  // (also orders the wtab zeroing / counting above; harmless extra barrier)
     uint32_t tot[PER], before[PER];
     uint32_t tsum = 0;
 #pragma unroll
@@ -129,7 +149,14 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__res
         tsum += tot[k];
         before[k] = 0;
     }
-    if (threadIdx.x * PER < BINS) {
+    if (BINS < kRsThreads) {
+        if ((int)threadIdx.x < BINS) {
+            uint32_t a = 0;
+#pragma unroll
+            for (int g = 0; g < RG; ++g) a += colsum[g * BINS + threadIdx.x];
+            before[0] = a;  // PER == 1 here
+        }
+    } else if (threadIdx.x * PER < BINS) {
         const uint32_t *col = hist + threadIdx.x * PER;
         uint32_t b = 0;
         for (; b + 8 <= blockIdx.x; b += 8) {  // 8 rows in flight per step
