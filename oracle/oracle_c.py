@@ -38,7 +38,9 @@ def lib():
     if _lib is None:
         if not os.path.exists(_SO):
             build()
-        L = C.CDLL(_SO)
+        # GM_ORACLE_SO: load another build of the same sources (the ASan/UBSan one: `make -C oracle
+        # libgm_oracle_asan.so`, run the CPU tests with LD_PRELOAD=$(gcc -print-file-name=libasan.so))
+        L = C.CDLL(os.environ.get("GM_ORACLE_SO", _SO))
         fp, ip, dp, u8p = (C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_uint8))
         L.gmo_crop_box.argtypes = [fp, C.c_int, C.c_double, ip]; L.gmo_crop_box.restype = C.c_int
         L.gmo_normals.argtypes = [fp, C.c_int, C.c_double, C.c_int, C.c_int, fp, ip]; L.gmo_normals.restype = C.c_int
