@@ -61,6 +61,28 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box shows all
+    256 hardware threads but grants a 16-CPU quota per GPU; more threads than that only get throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:     # cgroup v1
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(points, radius, threads):
     """The oracle (f32-faithful restatement of the reference's PCL/Eigen path), timed on
     this box's host cores on ONE frame of the same workload.  Baseline only."""
@@ -68,7 +90,7 @@ def cpu_baseline(points, radius, threads):
     from oracle import oracle_c as oc
     oc.build()
     xyz = synth.tunnel_frame(points, seed=0)
-    ncores = threads or (os.cpu_count() or 1)
+    ncores = threads or usable_cpus()
     t0 = time.perf_counter()
     oc.process_frame(xyz, 5.0, radius, 0.5, 0.2, oc.F32_FAITHFUL, nthreads=ncores, want_outputs=False)
     dt_all = time.perf_counter() - t0
