@@ -250,7 +250,7 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud)
     }
     launch_crop(rows, n, lo, hi, g, sl, s);
     record(ctx, sl, 2);
-    launch_grid_and_normals(g, vd, sl, n, (cf.flags & GM_CFG_KEEP_COUNTS) != 0, ctx->n_slots > 1, s);
+    launch_grid_and_normals(g, vd, sl, n, (cf.flags & GM_CFG_KEEP_COUNTS) != 0, s);
     record(ctx, sl, 3);  // end of grid+normals; the kernel alone is bracketed by ev_k0/ev_k1
     launch_compact_valid(sl, n, (float)ctx->own_lo, (float)ctx->own_hi, s);
     record(ctx, sl, 4);
@@ -744,7 +744,7 @@ gm_status gm_get_normals_stage(gm_ctx *ctx, const float *xyz, uint32_t n, double
     memset(&vd_off, 0, sizeof(vd_off));
     vd_off.own_lo = -std::numeric_limits<float>::infinity();
     vd_off.own_hi = std::numeric_limits<float>::infinity();
-    launch_grid_and_normals(g, vd_off, sl, n, (ctx->cfg.flags & GM_CFG_KEEP_COUNTS) != 0, false, sl.stream);
+    launch_grid_and_normals(g, vd_off, sl, n, (ctx->cfg.flags & GM_CFG_KEEP_COUNTS) != 0, sl.stream);
     launch_compact_valid(sl, n, -std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity(), sl.stream);
     uint32_t m[2] = {0, 0};
     GM_HIP(ctx, hipMemcpyAsync(m, &sl.ctr->n_cropped, 8, hipMemcpyDeviceToHost, sl.stream));

@@ -103,7 +103,7 @@ int launch_radix_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint
 uint32_t radix_hist_entries(uint32_t n_cap);
 // k_normals.hip
 void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, uint32_t n_cap, bool keep_counts,
-                             bool concurrent, hipStream_t s);
+                             hipStream_t s);
 uint32_t max_tiles(uint32_t n_cap, const GridParams &g);
 // k_frame.hip
 void launch_compact_valid(Slot &sl, uint32_t n_cap, float own_lo, float own_hi, hipStream_t s);

@@ -534,7 +534,7 @@ uint32_t max_tiles(uint32_t n_cap, const GridParams &g)
 }
 
 void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, uint32_t n_cap, bool keep_counts,
-                             bool concurrent, hipStream_t s)
+                             hipStream_t s)
 {
     if (n_cap == 0) return;
     // bits needed by the largest cell key
@@ -558,11 +558,11 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     const uint32_t mt = max_tiles(n_cap, g);
     uint32_t nb = (mt + kNrWaves - 1) / kNrWaves;
     {
-        // one wave per tile up to 65 536 blocks (262 144 tiles: a ~16 M-point frame), grid-stride beyond that
+        // one wave per tile up to 65 536 blocks (262 144 tiles: a ~16 M-point frame), grid-stride beyond that.
+        // GM_NORMALS_BLOCKS lowers the cap: tests use it to force the grid-stride path on a small frame.
         static const char *e = getenv("GM_NORMALS_BLOCKS");
         const uint32_t cap = e ? (uint32_t)atoi(e) : 65536u;
         if (nb > cap) nb = cap;
-        (void)concurrent;
     }
     // blocks per XCD chunk (0 = plain round-robin).  Measured on the 1 M frame: 32 keeps the kernel time of the plain
     // mapping with 29 % less L2 fill traffic; one contiguous eighth per XCD fetches 36 % less but runs 4 % longer
@@ -570,10 +570,8 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     static const char *xc = getenv("GM_NORMALS_XCD");
     VoxDense vdx = vd;
     vdx.xcd_chunk = xc ? (uint32_t)atoi(xc) : 32u;
-    static const char *dl = getenv("GM_NORMALS_DYNLDS");  // experiment knob: extra LDS per block lowers the blocks per CU
-    const uint32_t dyn_lds = dl ? (uint32_t)atoi(dl) : 0u;
     hipEventRecord(sl.ev_k0, s);
-    hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), dyn_lds, s, (const float4 *)sl.spts4, (const uint32_t *)skeys,
+    hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), 0, s, (const float4 *)sl.spts4, (const uint32_t *)skeys,
                        (const uint2 *)sl.tiles, sl.ctr, g, sl.tiles_cap, (const uint2 *)sl.row_bounds, sl.normals4,
                        keep_counts ? sl.counts : (int32_t *)nullptr, vdx, sl.vox_table);
     hipEventRecord(sl.ev_k1, s);
