@@ -70,7 +70,9 @@ GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, flo
     auto dim = [&](float e, float inv, int cap) { int n = (int)floorf(e * inv) + 1; return n < 1 ? 1 : (n > cap ? cap : n); };
     g.ny = dim(ey, g.inv_h, 1024); g.nz = dim(ez, g.inv_h, 1024);
     const int nxc = dim(ex, g.inv_h, 1024);
-    int fine = 16;
+    // x is binned 64x finer than y/z (measured on the 1 M frame: 8x 0.370 ms, 16x 0.345, 32x 0.337, 64x 0.328,
+    // 128x 0.329 for k_normals; beyond that the extra key bits cost the sort more than the windows gain)
+    int fine = 64;
     while (fine > 1 && (uint64_t)g.ny * g.nz * (uint64_t)(nxc * fine + fine) >= (1ull << 31)) fine >>= 1;
     g.inv_hx = g.inv_h * (float)fine;
     g.nx = dim(ex, g.inv_hx, 1024 * fine);

@@ -145,7 +145,9 @@ def test_get_normals_plane_known_answer(ctx):
     nrm, cloud, rows = ctx.getNormals(0.4, xyz)
     assert len(nrm) == len(xyz)
     assert ang(nrm[:, :3], nvec).max() < 2e-6
-    assert nrm[:, 3].max() < 1e-7
+    # exact value 0; the kernel adds <= 64-term fp32 partial sums of offsets into fp64 totals, so lambda0/trace is
+    # good to about two fp32 epsilons (1.19e-7 each), whatever order the sort leaves the candidates in
+    assert nrm[:, 3].max() < 2.5e-7
     assert ((-xyz.astype(np.float64) * nrm[:, :3]).sum(axis=1) >= 0).all()
 
 
