@@ -346,7 +346,10 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
     const uint32_t n_full = n_ptr ? *n_ptr : n_host;
     const uint32_t n = (n_full + stride - 1) / stride;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t slot = blockIdx.y * 64u + lane;  // which selected hypothesis this lane scores
+    // K <= 32 (the last stage): the wave's two halves score the SAME 32 hypotheses on different halves of the wave's
+    // points, so no lane idles in the most expensive stage; otherwise one hypothesis per lane, 64 per blockIdx.y
+    const bool split = K <= 32u;
+    const uint32_t slot = split ? (lane & 31u) : blockIdx.y * 64u + lane;  // which selected hypothesis this lane scores
     const uint32_t base = (blockIdx.x * 4u + wave) * PTS;
     const uint32_t m = base >= n ? 0u : ((n - base < (uint32_t)PTS) ? n - base : (uint32_t)PTS);
     const uint32_t groups = (m + 3u) >> 2;
@@ -375,7 +378,9 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
     }
     wave_lds_fence();  // every wave reads only the points it staged itself
     float c = 0.f;
-    for (uint32_t gi = 0; gi < groups; ++gi) {
+    // (every group of the wave's 64 is staged, points past the end as NaN, so a half-wave may read its 32 groups blind)
+    const uint32_t g0 = split ? (lane >> 5) * (PTS / 8) : 0u, g1 = split ? g0 + PTS / 8 : groups;
+    for (uint32_t gi = g0; gi < g1; ++gi) {
         const float4 X = lp[wave][gi][0], Y = lp[wave][gi][1], Z = lp[wave][gi][2];  // broadcast reads: 4 points
         const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
 #pragma unroll
@@ -386,8 +391,9 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
     }
     red[wave][lane] = c;
     __syncthreads();
-    if (wave == 0 && slot < K) {
-        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];  // exact: integers <= 1024
+    if (wave == 0 && slot < K && (!split || lane < 32u)) {
+        float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];  // exact: integers <= 1024
+        if (split) t += red[0][lane + 32] + red[1][lane + 32] + red[2][lane + 32] + red[3][lane + 32];
         if (t > 0.f) atomicAdd(&counts_k[slot], (int32_t)t);
     }
 }
