@@ -197,6 +197,23 @@ gm_status reset_counters(gm_ctx *ctx, Slot &sl)
     return GM_OK;
 }
 
+// Host rows -> device.  Page-locked input (GM_CLOUD_PINNED) is one DMA.  Pageable input goes through the slot's pinned
+// staging buffer in 2 MiB pieces: the calling thread copies piece k+1 while the DMA of piece k is in flight, so the
+// upload takes about max(memcpy, PCIe) instead of their sum; the caller's buffer is free again on return.
+static hipError_t upload_rows(Slot &sl, const gm_cloud *cloud, size_t raw_bytes, hipStream_t s)
+{
+    if (cloud->flags & GM_CLOUD_PINNED) return hipMemcpyAsync(sl.d_raw, cloud->data, raw_bytes, hipMemcpyHostToDevice, s);
+    const size_t piece = (size_t)2 << 20;
+    const uint8_t *src = (const uint8_t *)cloud->data;
+    for (size_t off = 0; off < raw_bytes; off += piece) {
+        const size_t len = raw_bytes - off < piece ? raw_bytes - off : piece;
+        memcpy(sl.h_raw + off, src + off, len);
+        const hipError_t e = hipMemcpyAsync(sl.d_raw + off, sl.h_raw + off, len, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud)
 {
     const uint32_t n = cloud->n_points;
@@ -216,12 +233,7 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud)
     record(ctx, sl, 0);
     const uint8_t *dev_rows = (const uint8_t *)cloud->data;
     if (!on_dev && n) {
-        const void *src = cloud->data;
-        if (!(cloud->flags & GM_CLOUD_PINNED)) {
-            memcpy(sl.h_raw, cloud->data, raw_bytes);  // pinned staging: the caller's buffer is free again on return
-            src = sl.h_raw;
-        }
-        GM_HIP(ctx, hipMemcpyAsync(sl.d_raw, src, raw_bytes, hipMemcpyHostToDevice, s));
+        GM_HIP(ctx, upload_rows(sl, cloud, raw_bytes, s));
         dev_rows = sl.d_raw;
     }
     record(ctx, sl, 1);
@@ -689,12 +701,7 @@ gm_status gm_chop_cloud(gm_ctx *ctx, const gm_cloud *cloud, double bound, float 
     if (st != GM_OK) return st;
     const uint8_t *dev_rows = (const uint8_t *)cloud->data;
     if (!on_dev && n) {
-        const void *src = cloud->data;
-        if (!(cloud->flags & GM_CLOUD_PINNED)) {
-            memcpy(sl.h_raw, cloud->data, raw_bytes);
-            src = sl.h_raw;
-        }
-        GM_HIP(ctx, hipMemcpyAsync(sl.d_raw, src, raw_bytes, hipMemcpyHostToDevice, sl.stream));
+        GM_HIP(ctx, upload_rows(sl, cloud, raw_bytes, sl.stream));
         dev_rows = sl.d_raw;
     }
     RowLayout rows;
