@@ -43,7 +43,12 @@ static inline uint32_t rs_blocks(uint32_t n_cap)
 }
 uint32_t radix_hist_entries(uint32_t n_cap)
 {
-    return (1u << kRsMaxBits) * (rs_blocks(n_cap) + 1) + kRsMaxPasses * (1u << kRsMaxBits);
+    // Sized for EVERY element count n <= n_cap, not just for n_cap: rs_blocks() is not monotonic (the tile doubles
+    // when items/thread steps up, so a 2.2 M-point capacity lays out 135 blocks where a 1.2 M-point frame lays out
+    // 147).  rs_blocks(n) <= ceil(n / (kRsBatch * kRsThreads)) and <= 256 for every n.
+    const uint64_t by_min_tile = ((uint64_t)n_cap + (uint64_t)kRsBatch * kRsThreads - 1) / ((uint64_t)kRsBatch * kRsThreads);
+    const uint32_t nb_max = (uint32_t)(by_min_tile < 256u ? by_min_tile : 256u);
+    return (1u << kRsMaxBits) * (nb_max + 1) + kRsMaxPasses * (1u << kRsMaxBits);
 }
 
 template <int BITS>

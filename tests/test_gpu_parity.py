@@ -380,3 +380,21 @@ def test_pinned_host_rows_equal_pageable_rows(gm, oc):
             assert np.array_equal(r["scatter"], ref[s][0])
             assert np.array_equal(c.normals(s), ref[s][1], equal_nan=True)
             assert np.array_equal(c.cropped_cloud(s)[0], ref[s][2])
+
+
+def test_frame_smaller_than_capacity_with_another_sort_layout(gm):
+    """The radix sort picks its tile from the element count, and the block count is NOT monotonic in it: a context
+    with a 2.1 M-point capacity lays out 129 blocks (16 keys per thread), a 1.9 M-point frame 232 (8 keys per thread).
+    The sort scratch must be sized for every count up to the capacity (regression: that frame used to run past the
+    histogram scratch and failed with hipErrorInvalidValue)."""
+    xyz = synth.tunnel_frame(1_900_000, seed=5, outlier_frac=0.01)
+    r = synth.fixed_k_radius(1_900_000)
+    with gm.GeometricMapping(neighborRadius=r, max_points=1_900_000) as c:
+        ref = c.process_frame(xyz)
+        ref_n = c.normals().copy()
+    with gm.GeometricMapping(neighborRadius=r, max_points=2_100_000) as c:     # capacity = exactly 2.1 M
+        c.process_frame(xyz[:1_000_000])
+        res = c.process_frame(xyz)
+        nrm = c.normals()
+    assert np.array_equal(res["scatter"], ref["scatter"]) and res["n_valid"] == ref["n_valid"]
+    assert np.array_equal(nrm, ref_n, equal_nan=True)
