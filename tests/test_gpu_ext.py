@@ -216,3 +216,21 @@ def test_full_size_properties_10m_plane_and_cylinder(gm, oc):
     # determinism at full size
     assert np.array_equal(lab, lab2) and res2["plane_inliers"] == res["plane_inliers"]
     assert np.array_equal(res2["scatter"], res["scatter"]) and np.array_equal(res2["cylinder"], res["cylinder"])
+
+
+@pytest.mark.parametrize("H", [32, 33, 256, 257])
+def test_frame_ransac_stage_boundaries(gm, oc, H):
+    """The staged scoring switches shape at H = 32 (exhaustive) and H = 256 (two stages instead of three): the plane
+    winner must equal the restated staging on the oracle's scorer on both sides of each boundary."""
+    from geometric_mapping_amd import _lib
+    xyz = synth.tunnel_frame(50000, seed=4, floor_z=-1.2, outlier_frac=0.01)
+    with gm.GeometricMapping(flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_RANSAC_PLANE, ransac_hypotheses=H,
+                             ransac_threshold=TAU, ransac_seed=11) as c:
+        res = c.process_frame(xyz)
+        cloud, _ = c.cropped_cloud()
+        lab = c.labels()
+    labels = np.zeros(len(cloud), np.uint8)
+    hp = oc.plane_hypotheses(cloud, 11, H, labels, 0)
+    bp, nbp = preemptive_best(oc.score_planes, cloud, hp, labels)
+    assert res["plane_inliers"] == nbp and np.abs(res["plane"] - hp[bp]).max() < 1e-5
+    assert oc.label_plane(cloud, labels, 0, 1, res["plane"], TAU) == nbp and np.array_equal(lab, labels)
