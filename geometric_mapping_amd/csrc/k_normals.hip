@@ -63,7 +63,10 @@ __device__ __forceinline__ v2f pk_within(v2f d2, v2f neg_big, v2f r2_big)
     return w;
 }
 
-constexpr int kNrThreads = 256;
+#ifndef GM_NRTHREADS
+#define GM_NRTHREADS 256
+#endif
+constexpr int kNrThreads = GM_NRTHREADS;
 constexpr int kTileQ = kWave;             // queries per tile: one per lane
 constexpr int kGroups = 4;                // lane groups with their own candidate window
 constexpr int kGroupLanes = kWave / kGroups;
