@@ -231,8 +231,6 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     }
     hipStream_t s = sl.stream;
     sl.n_in = n;
-    st = reset_counters(ctx, sl);
-    if (st != GM_OK) return st;
     record(ctx, sl, 0);
     const uint8_t *dev_rows = (const uint8_t *)cloud->data;
     if (!on_dev && n) {
@@ -263,11 +261,21 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
             GM_HIP(ctx, dmalloc(sl.vox_table, cells));
             sl.vox_table_cap = cells;
         }
-        GM_HIP(ctx, hipMemsetAsync(sl.vox_table, 0, (size_t)cells * sizeof(VoxCell), s));
+    }
+    {
+        // one zero-fill launch opens the frame: device counters, dense voxel table, per-row table of the search
+        // grid, digit totals of the sort (all only touched later in this frame, on this stream)
+        ZeroJobs z;
+        memset(&z, 0, sizeof(z));
+        z.ptr[0] = sl.ctr; z.words8[0] = sizeof(DevCounters) / 8;
+        if (vd.enabled) { z.ptr[1] = sl.vox_table; z.words8[1] = (uint64_t)vd.dim * vd.dim * vd.dim * sizeof(VoxCell) / 8; }
+        if (sl.row_bounds) { z.ptr[2] = sl.row_bounds; z.words8[2] = (uint64_t)g.ny * (uint64_t)g.nz; }  // (no buffers yet
+        if (sl.sort.hist) { z.ptr[3] = sl.sort.hist; z.words8[3] = radix_totals_bytes() / 8; }           //  before the first non-empty frame)
+        launch_zero_fill(z, s);
     }
     launch_crop(rows, n, lo, hi, g, sl, s);
     record(ctx, sl, 2);
-    launch_grid_and_normals(g, vd, sl, n, (cf.flags & GM_CFG_KEEP_COUNTS) != 0, s);
+    launch_grid_and_normals(g, vd, sl, n, (cf.flags & GM_CFG_KEEP_COUNTS) != 0, true, s);
     record(ctx, sl, 3);  // end of grid+normals; the kernel alone is bracketed by ev_k0/ev_k1
     launch_compact_valid(sl, n, (float)ctx->own_lo, (float)ctx->own_hi, s);
     record(ctx, sl, 4);
@@ -758,7 +766,7 @@ gm_status gm_get_normals_stage(gm_ctx *ctx, const float *xyz, uint32_t n, double
     memset(&vd_off, 0, sizeof(vd_off));
     vd_off.own_lo = -std::numeric_limits<float>::infinity();
     vd_off.own_hi = std::numeric_limits<float>::infinity();
-    launch_grid_and_normals(g, vd_off, sl, n, (ctx->cfg.flags & GM_CFG_KEEP_COUNTS) != 0, sl.stream);
+    launch_grid_and_normals(g, vd_off, sl, n, (ctx->cfg.flags & GM_CFG_KEEP_COUNTS) != 0, false, sl.stream);
     launch_compact_valid(sl, n, -std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity(), sl.stream);
     uint32_t m[2] = {0, 0};
     GM_HIP(ctx, hipMemcpyAsync(m, &sl.ctr->n_cropped, 8, hipMemcpyDeviceToHost, sl.stream));

@@ -98,12 +98,17 @@ constexpr int kScatterBlocks = 1024;
 void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const GridParams &g, Slot &sl, hipStream_t s);
 // k_sort.hip : stable LSD radix sort of (key,val) pairs; n is device-resident.
 // Returns 0 if the sorted data ends in (keys_a, vals_a), 1 if in (keys_b, vals_b).
+size_t radix_totals_bytes();
 int launch_radix_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
-                      const uint32_t *n_ptr, uint32_t n_cap, int key_bits, SortScratch &sc, hipStream_t s);
+                      const uint32_t *n_ptr, uint32_t n_cap, int key_bits, SortScratch &sc, bool totals_cleared,
+                      hipStream_t s);
 uint32_t radix_hist_entries(uint32_t n_cap);
 // k_normals.hip
 void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, uint32_t n_cap, bool keep_counts,
-                             hipStream_t s);
+                             bool scratch_cleared, hipStream_t s);
+// one launch that zero-fills up to four 8-byte-granular regions (the frame's counters and scratch tables)
+struct ZeroJobs { void *ptr[4]; uint64_t words8[4]; };
+void launch_zero_fill(const ZeroJobs &jobs, hipStream_t s);
 uint32_t max_tiles(uint32_t n_cap, const GridParams &g);
 // k_frame.hip
 void launch_compact_valid(Slot &sl, uint32_t n_cap, float own_lo, float own_hi, hipStream_t s);

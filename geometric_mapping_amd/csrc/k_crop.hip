@@ -71,6 +71,27 @@ struct CropEmit {
     }
 };
 
+__global__ __launch_bounds__(256) void k_zero_fill(ZeroJobs jobs)
+{
+    const uint2 z = make_uint2(0u, 0u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint2 *p = reinterpret_cast<uint2 *>(jobs.ptr[j]);
+        const uint64_t nw = jobs.words8[j];
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (uint64_t)gridDim.x * blockDim.x) p[i] = z;
+    }
+}
+
+void launch_zero_fill(const ZeroJobs &jobs, hipStream_t s)
+{
+    uint64_t most = 0;
+    for (int j = 0; j < 4; ++j) most = jobs.words8[j] > most ? jobs.words8[j] : most;
+    uint32_t nb = (uint32_t)((most + 255) / 256);
+    if (nb > 1024u) nb = 1024u;
+    if (nb == 0) nb = 1;
+    hipLaunchKernelGGL(k_zero_fill, dim3(nb), dim3(256), 0, s, jobs);
+}
+
 void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const GridParams &g, Slot &sl, hipStream_t s)
 {
     const uint32_t nb = compact_blocks(n);

@@ -537,7 +537,7 @@ uint32_t max_tiles(uint32_t n_cap, const GridParams &g)
 }
 
 void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, uint32_t n_cap, bool keep_counts,
-                             hipStream_t s)
+                             bool scratch_cleared, hipStream_t s)
 {
     if (n_cap == 0) return;
     // bits needed by the largest cell key
@@ -545,13 +545,13 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     int bits = 1;
     while ((1ull << bits) < ncell) ++bits;
     const int where = launch_radix_sort(sl.keys_a, sl.vals_a, sl.keys_b, sl.vals_b, &sl.ctr->n_cropped, n_cap, bits,
-                                        sl.sort, s);
+                                        sl.sort, scratch_cleared, s);
     uint32_t *skeys = where ? sl.keys_b : sl.keys_a;
     uint32_t *perm = where ? sl.vals_b : sl.vals_a;
     sl.skeys = skeys;
     const uint32_t gb = (n_cap + 255) / 256 < 2048 ? (n_cap + 255) / 256 : 2048;
     // rows the frame leaves unoccupied must read as empty ranges in k_normals' window searches
-    hipMemsetAsync(sl.row_bounds, 0, sizeof(uint2) * (size_t)g.ny * (size_t)g.nz, s);
+    if (!scratch_cleared) hipMemsetAsync(sl.row_bounds, 0, sizeof(uint2) * (size_t)g.ny * (size_t)g.nz, s);
     hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(256), 0, s, (const float4 *)sl.crop4, (const uint32_t *)perm,
                        (const uint32_t *)skeys, (const uint32_t *)&sl.ctr->n_cropped, (uint32_t)g.nx, sl.spts4,
                        sl.row_bounds);

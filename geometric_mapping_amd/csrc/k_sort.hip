@@ -250,8 +250,12 @@ static void rs_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, ui
                        (const uint32_t *)hist, (const uint32_t *)totals);
 }
 
+// scratch layout: [digit totals: kRsMaxPasses x 2^kRsMaxBits words][histogram rows: blocks x bins]
+size_t radix_totals_bytes() { return sizeof(uint32_t) * kRsMaxPasses * (1u << kRsMaxBits); }
+
 int launch_radix_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
-                      const uint32_t *n_ptr, uint32_t n_cap, int key_bits, SortScratch &sc, hipStream_t s)
+                      const uint32_t *n_ptr, uint32_t n_cap, int key_bits, SortScratch &sc, bool totals_cleared,
+                      hipStream_t s)
 {
     const uint32_t nb = rs_blocks(n_cap);
     if (nb == 0) return 0;
@@ -261,9 +265,9 @@ int launch_radix_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint
     int bits = (key_bits + passes - 1) / passes;  // spread the bits evenly
     if (bits < 8) bits = 8;
     const uint32_t items = rs_items(n_cap);
-    uint32_t *hist = sc.hist;
-    uint32_t *totals = sc.hist + (size_t)(1u << kRsMaxBits) * (nb + 1);
-    hipMemsetAsync(totals, 0, sizeof(uint32_t) * kRsMaxPasses * (1u << kRsMaxBits), s);
+    uint32_t *totals = sc.hist;  // fixed place: the frame's opening zero-fill clears it (totals_cleared)
+    uint32_t *hist = sc.hist + (size_t)kRsMaxPasses * (1u << kRsMaxBits);
+    if (!totals_cleared) hipMemsetAsync(totals, 0, radix_totals_bytes(), s);
     const uint32_t *kin = keys_a, *vin = nullptr /* first pass: value = index */;
     uint32_t *kout = keys_b, *vout = vals_b;
     for (int p = 0; p < passes; ++p) {

@@ -133,7 +133,7 @@ void launch_voxel_grid(Slot &sl, uint32_t n_cap, float leaf, int key_bits, hipSt
     hipLaunchKernelGGL(k_voxel_keys, dim3(gb), dim3(256), 0, s, (const float4 *)sl.valid4, (const DevCounters *)sl.ctr,
                        (const VoxelParams *)sl.voxp, sl.keys_a);
     const int where = launch_radix_sort(sl.keys_a, sl.vals_a, sl.keys_b, sl.vals_b, &sl.ctr->vox_n, n_cap, key_bits,
-                                        sl.sort, s);
+                                        sl.sort, false, s);
     const uint32_t *skeys = where ? sl.keys_b : sl.keys_a;
     const uint32_t *perm = where ? sl.vals_b : sl.vals_a;
     const uint32_t nb = compact_blocks(n_cap);
