@@ -267,6 +267,9 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
         if (t >= ntiles) break;  // every wave reaches this: the tile list is final before the launch
         const uint2 tile = tiles[t];
         const uint32_t qs = tile.x, qn = tile.y;  // first query (sorted position), number of queries (1..64)
+#ifdef GM_NORMALS_TIMELINE
+        const unsigned long long stat_t0 = wall_clock64();
+#endif
 
         // this lane's query and its fine x cell (keys inside a tile are ascending: lanes are x-sorted)
         const int ql = lane;
@@ -488,6 +491,13 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
             }
             normals4[dst] = out;
             if (counts) counts[dst] = cnt;
+#ifdef GM_NORMALS_TIMELINE  // diagnostic build (tools/tile_timeline.py): lanes 0 / 1 of a tile report its end tick / duration
+            {
+                const unsigned long long t1 = wall_clock64();
+                if (counts && qn >= 2 && lane == 0) counts[dst] = -(int)((t1 & 0x1FFFFFFFull) | 0x20000000ull);  // end tick, bit 29 set
+                if (counts && qn >= 2 && lane == 1) counts[dst] = -(int)((t1 - stat_t0) & 0xFFFFFull) - 1;        // duration < 2^20 ticks
+            }
+#endif
         }
 
         // ---- VoxelGrid fast path: points of a tile are spatial neighbours, so they fall
