@@ -171,11 +171,21 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
     return GM_OK;
 }
 
+// x/y/z must lie inside a row; 64-bit arithmetic so that an offset near 2^32 cannot wrap past the check.  Called
+// before anything of the frame is enqueued (no DMA may be in flight from the caller's buffer on an error return).
+gm_status check_layout(gm_ctx *ctx, const gm_cloud *c)
+{
+    const uint64_t step = c->point_step;
+    if (c->n_points && (step < 12 || (uint64_t)c->off_x + 4 > step || (uint64_t)c->off_y + 4 > step ||
+                        (uint64_t)c->off_z + 4 > step))
+        return fail(ctx, GM_ERR_INVALID_ARG, "gm_cloud: x/y/z offsets do not fit in point_step");
+    return GM_OK;
+}
+
 gm_status make_rows(gm_ctx *ctx, const gm_cloud *c, const uint8_t *dev_data, RowLayout &rows)
 {
-    if (c->n_points && (c->point_step < 12 || c->off_x + 4 > c->point_step || c->off_y + 4 > c->point_step ||
-                        c->off_z + 4 > c->point_step))
-        return fail(ctx, GM_ERR_INVALID_ARG, "gm_cloud: x/y/z offsets do not fit in point_step");
+    const gm_status lst = check_layout(ctx, c);
+    if (lst != GM_OK) return lst;
     rows.data = dev_data;
     rows.step = c->point_step; rows.ox = c->off_x; rows.oy = c->off_y; rows.oz = c->off_z;
     rows.bswap = (c->flags & GM_CLOUD_BIGENDIAN) ? 1u : 0u;
@@ -223,7 +233,11 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     const size_t raw_bytes = (size_t)n * cloud->point_step;
     const bool on_dev = (cloud->flags & GM_CLOUD_DEVICE) != 0;
     if (n && !cloud->data) return fail(ctx, GM_ERR_INVALID_ARG, "gm_cloud.data is NULL");
-    gm_status st = ensure_capacity(ctx, sl, n, raw_bytes, !on_dev);
+    gm_status st = check_layout(ctx, cloud);
+    if (st != GM_OK) return st;
+    // n == 0 still sizes the buffers for one point: every stage below may then assume non-null scratch (an empty
+    // cloud as the very first frame of a context used to reach k_compact_count with block_counts == nullptr)
+    st = ensure_capacity(ctx, sl, n ? n : 1u, raw_bytes, !on_dev);
     if (st != GM_OK) return st;
     if (ctx->cfg.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER | GM_CFG_NEAREST)) {
         st = gm_ensure_ext(ctx, sl, ctx->cfg.ransac_hypotheses ? ctx->cfg.ransac_hypotheses : 1);
@@ -281,6 +295,7 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     record(ctx, sl, 4);
     const uint32_t nparts = launch_scatter_partials(sl.vnorm4, &sl.ctr->n_valid, n, cf.weightingFactor, sl, s);
     record(ctx, sl, 5);
+    sl.vox_sort_path = (cf.flags & GM_CFG_VOXEL_GRID) && !vd.enabled;
     if (cf.flags & GM_CFG_VOXEL_GRID) {
         if (vd.enabled) {
             launch_voxel_dense_finalize(vd, sl, s);
@@ -321,7 +336,8 @@ void fill_result(gm_ctx *ctx, Slot &sl, gm_frame_result *r)
     for (int k = 0; k < 9; ++k) r->eigenvectors[k] = o.evecs[k];
     for (int k = 0; k < 3; ++k) r->center_axis[k] = o.evecs[k];  // block<3,1>(0,0)
     for (int k = 0; k < 6; ++k) r->scatter[k] = o.scatter[k];
-    if ((ctx->cfg.flags & GM_CFG_VOXEL_GRID) && o.vox.passthrough) r->status_flags |= GM_RES_VOXEL_PASSTHROUGH;
+    // (the dense-table path never passes through; voxp may still hold the flag of an earlier gm_voxel_grid stage call)
+    if (sl.vox_sort_path && o.vox.passthrough) r->status_flags |= GM_RES_VOXEL_PASSTHROUGH;
     if (ctx->cfg.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)) {
         r->plane_inliers = o.ext.plane_inliers;
         r->cylinder_inliers = o.ext.cylinder_inliers;
@@ -407,8 +423,11 @@ gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H)
     hipFree(sl.hyp_plane); hipFree(sl.hyp_cyl); hipFree(sl.band); hipFree(sl.score_partial); hipFree(sl.cnt_plane);
     hipFree(sl.cnt_cyl); hipFree(sl.best_plane); hipFree(sl.best_cyl); hipFree(sl.mom_partial); hipFree(sl.mom_plane);
     hipFree(sl.mom_cyl); hipFree(sl.nn_best);
-    sl.ext_H = 0; sl.ext_cap = 0;
+    // (a failed allocation below must not leave dangling pointers for gm_destroy to free again)
+    sl.hyp_plane = sl.hyp_cyl = nullptr; sl.band = nullptr; sl.score_partial = nullptr; sl.cnt_plane = sl.cnt_cyl = nullptr;
+    sl.best_plane = sl.best_cyl = nullptr; sl.mom_partial = sl.mom_plane = sl.mom_cyl = nullptr; sl.nn_best = nullptr;
     const uint32_t HH = H > sl.ext_H ? H : sl.ext_H;
+    sl.ext_H = 0; sl.ext_cap = 0;
     GM_HIP(ctx, dmalloc(sl.hyp_plane, (size_t)HH * 8)); GM_HIP(ctx, dmalloc(sl.hyp_cyl, (size_t)HH * 8));
     GM_HIP(ctx, dmalloc(sl.band, HH));
     GM_HIP(ctx, dmalloc(sl.score_partial, (size_t)1024));  // pre-selection scratch (k_ransac.hip kPreScratchWords = 576)
@@ -541,6 +560,10 @@ gm_status gm_create(const gm_config *cfg, gm_ctx **out)
     if (!(cfg->weightingFactor != 0.0) || !std::isfinite(cfg->boxFilterBound) || !(cfg->boxFilterBound >= 0.0) ||
         !(cfg->voxelGridLeafSize > 0.0) || !radius_ok(cfg->neighborRadius))
         return fail(nullptr, GM_ERR_INVALID_ARG, "gm_config: bad numeric parameter");
+    if ((cfg->flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)) &&
+        (cfg->ransac_hypotheses == 0 || cfg->ransac_hypotheses > kMaxHypotheses || !(cfg->ransac_threshold > 0.0) ||
+         !std::isfinite(cfg->ransac_threshold)))
+        return fail(nullptr, GM_ERR_INVALID_ARG, "gm_config: ransac_hypotheses must be in [1, 8192] and ransac_threshold > 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, GM_ERR_DEVICE, "no HIP device visible (libgm_hip has no CPU fallback)");
@@ -708,7 +731,9 @@ gm_status gm_chop_cloud(gm_ctx *ctx, const gm_cloud *cloud, double bound, float 
     const size_t raw_bytes = (size_t)n * cloud->point_step;
     const bool on_dev = (cloud->flags & GM_CLOUD_DEVICE) != 0;
     if (n && !cloud->data) return fail(ctx, GM_ERR_INVALID_ARG, "gm_cloud.data is NULL");
-    st = ensure_capacity(ctx, sl, n, raw_bytes, !on_dev);
+    st = check_layout(ctx, cloud);
+    if (st != GM_OK) return st;
+    st = ensure_capacity(ctx, sl, n ? n : 1u, raw_bytes, !on_dev);
     if (st != GM_OK) return st;
     st = reset_counters(ctx, sl);
     if (st != GM_OK) return st;

@@ -72,6 +72,7 @@ struct Slot {
     unsigned long long *nn_best = nullptr;            // [cap]
     // state
     bool submitted = false, complete = false;
+    bool vox_sort_path = false;  // this frame's voxels came from the sort path (may report passthrough)
     uint32_t n_in = 0;
     gm_frame_result last = {};
 };

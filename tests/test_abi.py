@@ -68,6 +68,12 @@ def test_create_rejects_bad_arguments_and_never_falls_back():
     cfg.voxelGridLeafSize = 0.0
     assert L.gm_create(C.byref(cfg), C.byref(ctx)) == _lib.GM_ERR_INVALID_ARG
     assert b"numeric" in L.gm_last_error(None)
+    for h, tau in ((0, 0.03), (8193, 0.03), (64, 0.0), (64, float("nan"))):   # RANSAC parameters are checked at creation
+        L.gm_default_config(C.byref(cfg))
+        cfg.flags |= _lib.GM_CFG_RANSAC_CYLINDER
+        cfg.ransac_hypotheses, cfg.ransac_threshold = h, tau
+        assert L.gm_create(C.byref(cfg), C.byref(ctx)) == _lib.GM_ERR_INVALID_ARG
+        assert b"ransac" in L.gm_last_error(None)
     L.gm_default_config(C.byref(cfg))
     st = L.gm_create(C.byref(cfg), C.byref(ctx))
     if st == _lib.GM_OK:          # running on a GPU box

@@ -271,6 +271,36 @@ def test_process_frame_edge_cases(ctx):
     assert r["n_in"] == 777 and 0 < r["n_cropped"] <= 777
 
 
+@pytest.mark.parametrize("ransac", [False, True])
+def test_empty_cloud_as_the_very_first_frame(gm, ransac):
+    """A sensor that publishes an empty cloud first: a FRESH context (no buffers yet, max_points = 0) must come
+    through every stage with null-free scratch (regression: k_compact_count<DensePred> wrote through sl.blk == NULL)."""
+    from geometric_mapping_amd import _lib
+    flags = _lib.GM_CFG_DEFAULT | _lib.GM_CFG_NEAREST
+    if ransac:
+        flags |= _lib.GM_CFG_RANSAC_PLANE | _lib.GM_CFG_RANSAC_CYLINDER
+    with gm.GeometricMapping(flags=flags) as c:
+        r = c.process_frame(np.zeros((0, 3), np.float32))
+        assert r["n_in"] == 0 and r["n_cropped"] == 0 and r["n_valid"] == 0 and r["n_voxels"] == 0
+        assert np.all(r["eigenvalues"] == 0)
+        if ransac:
+            assert r["plane_inliers"] == 0 and r["cylinder_inliers"] == 0
+        r = c.process_frame(synth.tunnel_frame(5000, seed=4))      # and the context is still usable
+        assert r["n_valid"] > 0
+
+
+def test_voxel_passthrough_flag_does_not_leak_into_frames(gm):
+    """gm_voxel_grid (sort path) may raise GM_RES_VOXEL_PASSTHROUGH; a later frame on the dense-table path must not
+    report the stale flag."""
+    from geometric_mapping_amd import _lib
+    with gm.GeometricMapping() as c:
+        pts = np.array([[0, 0, 0], [1000, 1000, 1000]], np.float32)
+        _, _, passed = c.voxelGrid(1e-3, pts)
+        assert passed
+        r = c.process_frame(synth.tunnel_frame(5000, seed=4))
+        assert not (r["status_flags"] & _lib.GM_RES_VOXEL_PASSTHROUGH)
+
+
 def test_process_frame_device_resident_rows(ctx, oc):
     torch = pytest.importorskip("torch")
     xyz = synth.tunnel_frame(30000, seed=3)
