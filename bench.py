@@ -20,7 +20,15 @@ N > 1 (one process per GPU, RCCL via torch.distributed):
       processes its slab, all-gathers a 10-double record (scatter partials + counts)
       over RCCL and solves the merged 3x3.  scaling = strong.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Besides the contract's keys it carries
+  per_frame         SURVEY par. 8(d) / BASELINE.md par. 3 protocol: ONE blocking gm_process_frame per frame, rows handed
+                    over as a HOST buffer (H2D inside), median / p10 / p90 of >= 20 frames after 3 warm-ups; pageable and
+                    page-locked input, with and without the /choppedCloud D2H, and device-resident rows (kernels only)
+  stress_launch_literal   the reference's own launch value neighborRadius = 0.5 on the same 1 M frame (k ~ 5 100)
+  cpu_config1       BASELINE configs[0]: 50 k points, r = 0.5, oracle f32_faithful on 1 thread and on all usable cores
+`value` itself stays the whole-job rate with the rows resident in HBM (the round contract: a PCIe-inclusive rate
+is never `value`); `roofline.frac` uses the kernel's EXCLUSIVE duration (frames one at a time), the figure rocprofv3's
+kernel stats show, and the PMC numbers are read from profiles/r<tag>_* of the newest round that holds them.
 """
 from __future__ import annotations
 
@@ -58,7 +66,31 @@ def parse():
                     help="nccl (= RCCL) is the real thing; gloo only rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this device")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--frames", type=int, default=24, help="frames of the per-frame (blocking, H2D-inclusive) protocol")
+    ap.add_argument("--profile-tag", default=None, help="rNN prefix of the profiles/ files to quote (default: newest)")
     return ap.parse_args()
+
+
+def profile_path(name, tag=None):
+    """profiles/<tag>_<name>; without a tag the newest round that holds the file."""
+    import glob
+    import re
+    if tag:
+        p = os.path.join(ROOT, "profiles", f"{tag}_{name}")
+        return p if os.path.exists(p) else None
+    best = None
+    for p in glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{name}")):
+        m = re.search(r"r(\d\d)_", os.path.basename(p))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), p)
+    return best[1] if best else None
+
+
+def quantiles(ms, n_points):
+    a = np.asarray(ms, dtype=np.float64)
+    med = float(np.median(a))
+    return {"frames": int(a.size), "median_ms": med, "p10_ms": float(np.quantile(a, 0.1)), "p90_ms": float(np.quantile(a, 0.9)),
+            "points_per_s": n_points / (med * 1e-3)}
 
 
 def usable_cpus():
@@ -107,6 +139,24 @@ def cpu_baseline(points, radius, threads):
             "single_thread_sample": f"{points // 5} pts at matched k (r*sqrt(5)), 1 thread"}
 
 
+def cpu_config1(threads):
+    """BASELINE configs[0]: the 50 k-point frame with the launch file's own values (r = 0.5), oracle f32_faithful on one
+    thread (how the reference runs: ros::spin + non-OMP NormalEstimation) and on every usable core."""
+    from geometric_mapping_amd import synth
+    from oracle import oracle_c as oc
+    oc.build()
+    xyz = synth.tunnel_frame(50000, seed=0)
+    out = {"points": 50000, "radius": 0.5, "kind": "port"}
+    for name, nt in (("one_thread", 1), ("all_cores", threads or usable_cpus())):
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            oc.process_frame(xyz, 5.0, 0.5, 0.5, 0.2, oc.F32_FAITHFUL, nthreads=nt, want_outputs=False)
+            ts.append(time.perf_counter() - t0)
+        out[name] = {"threads": int(nt), "median_ms": float(np.median(ts)) * 1e3, "points_per_s": 50000 / float(np.median(ts))}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,7 +189,7 @@ def main():
     n = args.points
     radius = args.radius if args.radius else synth.fixed_k_radius(n)
     bound, leaf, wf = 5.0, 0.5, 0.2
-    flags = _lib.GM_CFG_DEFAULT | _lib.GM_CFG_STAGE_TIMING
+    flags = _lib.GM_CFG_DEFAULT   # no per-stage events inside the timed region; a separate short run reads them
     ransac_on = False
     if args.ransac:
         probe = g.load_library()
@@ -239,9 +289,9 @@ def main():
             if results is not None:
                 results.append(r)
 
-    def timed(c, inputs, slots):
+    def timed(c, inputs, slots, min_warmup=0):
         res = []
-        run(c, inputs, args.warmup, slots, None)
+        run(c, inputs, max(args.warmup, min_warmup), slots, None)
         barrier()
         t0 = time.perf_counter()
         run(c, inputs, args.steps, slots, res)
@@ -262,67 +312,106 @@ def main():
     value = total_points / dt
 
     secondary = {}
+    k_ms_excl = None
+    if mode == "frames":
+        # the dominant kernel with the chip to itself: frames one at a time, hipEvents on the slot's own stream
+        ex = [ctx.process_frame(clouds[i % len(clouds)])["normals_kernel_ms"] for i in range(max(10, min(args.steps, 30)))]
+        k_ms_excl = float(np.mean(ex[2:]))
     if not args.no_secondary and world == 1:
         if ransac_on:  # the reference-faithful path alone (no extension work in the step)
             with make_ctx(_lib.GM_CFG_DEFAULT, n_slots) as c2:
                 dt2, _ = timed(c2, clouds, n_slots)
             secondary["reference_faithful_path_only"] = {"value": n * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3}
-        # rows handed over as HOST buffers (what the ROS node does): pinned staging + H2D inside the step.
-        # Never the headline value (DESIGN.md par. 7).
-        host_inputs = [ctx._cloud_from_xyz(rows16(f)) for f in frames_host] if mode == "frames" else None
-        if host_inputs:
-            dt3, _ = timed(ctx, host_inputs, n_slots)
-            secondary["host_input_pcie_inclusive"] = {"value": n * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3,
-                                                      "input": "pageable host rows: staging copy on the calling thread + H2D"}
-            # the same with rows the caller already holds in page-locked memory (gm_host_alloc, GM_CLOUD_PINNED)
-            pinned_inputs = []
-            for f in frames_host:
-                r16 = rows16(f)
-                buf, as_cloud = ctx.pinned_rows(r16.shape[0], 16)
-                buf[:] = r16.reshape(-1).view(np.uint8)
-                pinned_inputs.append(as_cloud())
-            for pc in pinned_inputs:   # a page-locked buffer's first DMA pays a one-time mapping cost: not steady state
-                ctx.process_frame(pc)
-            dt4, _ = timed(ctx, pinned_inputs, n_slots)
-            secondary["host_input_pinned_pcie_inclusive"] = {"value": n * args.steps / dt4, "ms_per_step": dt4 / args.steps * 1e3,
-                                                             "input": "page-locked host rows (GM_CLOUD_PINNED): H2D only"}
+        # per-stage device times of one frame alone (events on; outside every timed region)
+        with make_ctx(flags | _lib.GM_CFG_STAGE_TIMING, 1) as c3:
+            for _ in range(3):
+                c3.process_frame(clouds[0])
+            st = [c3.process_frame(clouds[i % len(clouds)])["stage_ms"] for i in range(8)]
+            secondary["stage_ms_one_frame_alone"] = {k: round(float(np.median([x[k] for x in st])), 4) for k in st[0]}
+        host_rows = [rows16(f) for f in frames_host]
+        host_inputs = [ctx._cloud_from_xyz(r16) for r16 in host_rows]
+        pinned_inputs = []
+        for r16 in host_rows:
+            buf, as_cloud = ctx.pinned_rows(r16.shape[0], 16)
+            buf[:] = r16.reshape(-1).view(np.uint8)
+            pinned_inputs.append(as_cloud())
+        # ---- SURVEY par. 8(d) protocol: one blocking call per frame, median / p10 / p90
+        def per_frame(inputs, fetch_cloud=False):
+            ms = []
+            for i in range(3 + args.frames):
+                t0 = time.perf_counter()
+                ctx.process_frame(inputs[i % len(inputs)])
+                if fetch_cloud:
+                    ctx.cropped_cloud()
+                if i >= 3:
+                    ms.append((time.perf_counter() - t0) * 1e3)
+            return quantiles(ms, n)
+        # (a page-locked buffer's first DMA on a stream pays a one-time mapping cost: every (slot, buffer) pair is
+        #  touched once before anything is timed -- with 20 timed steps that cost used to sit inside the timed region)
+        for sl in range(n_slots):
+            for pc in pinned_inputs + host_inputs:
+                ctx.submit_frame(sl, pc)
+                ctx.wait_frame(sl)
+        secondary["per_frame"] = {
+            "protocol": f"blocking gm_process_frame per frame, 3 warm-ups, {args.frames} timed frames, wall clock of the call",
+            "host_rows_pageable": per_frame(host_inputs),
+            "host_rows_pinned": per_frame(pinned_inputs),
+            "host_rows_pinned_plus_choppedCloud_d2h": per_frame(pinned_inputs, fetch_cloud=True),
+            "device_resident_rows": per_frame(clouds),
+        }
+        # rows handed over as HOST buffers with frames in flight (never the headline value)
+        dt3, _ = timed(ctx, host_inputs, n_slots, min_warmup=4 * n_slots)
+        secondary["host_input_pcie_inclusive"] = {"value": n * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3,
+                                                  "input": "pageable host rows: staging copy on the calling thread + H2D"}
+        dt4, _ = timed(ctx, pinned_inputs, n_slots, min_warmup=4 * n_slots)
+        secondary["host_input_pinned_pcie_inclusive"] = {"value": n * args.steps / dt4, "ms_per_step": dt4 / args.steps * 1e3,
+                                                         "input": "page-locked host rows (GM_CLOUD_PINNED): H2D only"}
+        # ---- stress row: the reference's own launch value (launch/mapping.launch:9), k ~ 5 100 at 1 M points
+        with g.GeometricMapping(boxFilterBound=bound, voxelGridLeafSize=leaf, neighborRadius=0.5, weightingFactor=wf,
+                                device=local_rank, flags=_lib.GM_CFG_DEFAULT, n_slots=1, max_points=n) as c4:
+            c4.process_frame(clouds[0])
+            ms, km = [], []
+            for i in range(5):
+                t0 = time.perf_counter()
+                r4 = c4.process_frame(clouds[i % len(clouds)])
+                ms.append((time.perf_counter() - t0) * 1e3)
+                km.append(r4["normals_kernel_ms"])
+            secondary["stress_launch_literal"] = {"neighborRadius": 0.5, "k_regime": "launch-literal (~5 100 neighbours)",
+                                                  "normals_kernel_ms": float(np.median(km)), "frame_ms": float(np.median(ms)),
+                                                  "points_per_s": n / (float(np.median(ms)) * 1e-3), "input": "rows resident in HBM"}
 
-    # the same kernel with the chip to itself: frames one at a time (this is also what the kernel sees under
-    # rocprofv3, whose host-side overhead keeps the frames from overlapping: profiles/README.md)
-    k_ms_excl = None
-    if mode == "frames":
-        ex = [ctx.process_frame(clouds[i % len(clouds)])["normals_kernel_ms"] for i in range(min(args.steps, 10))]
-        k_ms_excl = float(np.mean(ex))
-
-    # dominant kernel: the neighbourhood-normals kernel, HIP-event bracketed on the stream
-    # it runs on, inside the timed region (gm_frame_result.normals_kernel_ms)
+    # dominant kernel: the neighbourhood-normals kernel, HIP-event bracketed on the stream it runs on
+    # (gm_frame_result.normals_kernel_ms): in the timed region it shares the chip with the other frames in flight,
+    # the roofline uses its exclusive duration (what rocprofv3's kernel stats of this command show)
     k_ms = float(np.mean([r["normals_kernel_ms"] for r in results])) if results else 0.0
     n_crop = float(np.mean([r["n_cropped"] for r in results])) if results else 0.0
     algo_bytes = 28.0 * n_crop                      # SURVEY par. 8d: normals = 12 N' read + 16 N' written
-    achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "r01_normals_pmc.json")
-    if os.path.exists(prof) and mode == "frames":
+    k_roof = k_ms_excl if k_ms_excl else k_ms
+    achieved = algo_bytes / (k_roof * 1e-3) / 1e9 if k_roof > 0 else 0.0
+    traffic, traffic_src = None, None
+    prof = profile_path("normals_pmc.json", args.profile_tag)
+    if prof and mode == "frames":
         try:
             with open(prof) as f:
                 pj = json.load(f)
             if pj.get("points") == n and abs(pj.get("radius", 0) - radius) < 1e-9:
-                traffic = pj.get("hbm_bytes_per_launch")
+                traffic, traffic_src = pj.get("hbm_bytes_per_launch"), os.path.relpath(prof, ROOT)
         except Exception:
             traffic = None
-    # the kernel's real bound: fp32 VALU issue.  Busy fraction from committed PMC counters (same workload); the
-    # live part is the lane-operation rate implied by the instruction count of that profile and THIS run's duration.
+    # the kernel's real bound is instruction issue (VALU + MFMA), not HBM: busy fractions from the committed PMC pass
+    # of the same workload; the live part is the instruction rate implied by that count and THIS run's duration
     valu = None
-    vprof = os.path.join(ROOT, "profiles", "r01_normals_valu_pmc.json")
-    if os.path.exists(vprof) and traffic is not None:
+    vprof = profile_path("normals_valu_pmc.json", args.profile_tag)
+    if vprof and mode == "frames":
         try:
             with open(vprof) as f:
                 vj = json.load(f)
             insts = float(vj["counters"]["SQ_INSTS_VALU"])
             valu = {"valu_busy_frac_pmc": vj["derived"]["valu_busy_frac"], "SQ_INSTS_VALU_per_launch": insts,
-                    "wave_instr_per_s": insts / (k_ms_excl * 1e-3) if k_ms_excl else None,
+                    "wave_instr_per_s": insts / (k_roof * 1e-3) if k_roof else None,
                     "peak_wave_instr_per_s_packed": 1024 * 2.4e9 / 4.0,
-                    "source": "profiles/r01_normals_valu_pmc.json, profiles/r01_valu_rate_probe.txt"}
+                    "mfma_busy_frac_pmc": vj["derived"].get("mfma_busy_frac"),
+                    "source": os.path.relpath(vprof, ROOT)}
         except Exception:
             valu = None
 
@@ -338,22 +427,24 @@ def main():
                        "voxelGridLeafSize": leaf, "weightingFactor": wf, "mode": mode, "frames_in_flight": n_slots,
                        "ransac_model": "cylinder, H=1024, tau=0.03 (extension)" if ransac_on else "none (reference-faithful path)",
                        "parallelism": f"{mode}x{world}", "collective_backend": args.dist_backend if world > 1 else None},
-            "roofline": {"kernel": "k_normals", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": k_ms, "avg_launch_ms_exclusive": k_ms_excl,
-                         "algorithmic_bytes_per_launch": algo_bytes, "valu": valu,
-                         "note": "VALU-bound neighbour loop (k~256): HBM fraction is reported as the contract asks, see "
-                                 "DESIGN.md par. 4 for its VALU roofline. avg_launch_ms is hipEvent-bracketed inside the timed "
-                                 "region, where the kernel shares the chip with the other frames in flight; "
-                                 "avg_launch_ms_exclusive (frames one at a time) is the figure rocprofv3's kernel stats show"},
+            "roofline": {"kernel": os.environ.get("GM_NORMALS_IMPL", "mfma")[0] == "v" and "k_normals" or "k_normals_mx",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_launch_ms": k_roof, "avg_launch_ms_in_pipeline": k_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes, "issue": valu,
+                         "note": "compute-bound neighbour loop (k~256, predicate on the VALU, moments on the matrix cores): the HBM "
+                                 "fraction is reported as the contract asks, DESIGN.md par. 4 holds its issue-rate roofline. "
+                                 "avg_launch_ms = hipEvent bracket with frames one at a time (= rocprofv3 kernel stats of this "
+                                 "command); avg_launch_ms_in_pipeline = the same bracket inside the timed region, where the "
+                                 "kernel shares the chip with the other frames in flight"},
             "whole_path_hbm": {"algorithmic_bytes_per_point": ALGO_BYTES_PER_POINT,
                                "achieved_GBs": value * ALGO_BYTES_PER_POINT / 1e9,
                                "frac_of_spec": value * ALGO_BYTES_PER_POINT / 1e9 / HBM_PEAK_GBS},
-            "stage_ms_last_frame": {k: round(v, 4) for k, v in results[-1]["stage_ms"].items()} if results else {},
         }
         out.update(secondary)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, radius, args.cpu_threads)
+            out["cpu_config1"] = cpu_config1(args.cpu_threads)
         print(json.dumps(out))
     ctx.close()
     if world > 1:

@@ -133,6 +133,7 @@ def load():
         "gm_get_normals": (C.c_int, [vp, u32, fp, u32, u32p]),
         "gm_get_voxel_centroids": (C.c_int, [vp, u32, fp, u32, u32p]),
         "gm_get_voxel_nearest": (C.c_int, [vp, u32, i32p, u32, u32p]),
+        "gm_get_voxel_normals": (C.c_int, [vp, u32, fp, u32, u32p]),
         "gm_get_neighbor_counts": (C.c_int, [vp, u32, i32p, u32, u32p]),
         "gm_get_labels": (C.c_int, [vp, u32, u8p, u32, u32p]),
         "gm_chop_cloud": (C.c_int, [vp, cloudp, C.c_double, fp, u32, u32p]),

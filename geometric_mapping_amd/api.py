@@ -188,6 +188,10 @@ class GeometricMapping:
         """Index (into cropped_cloud()) of the nearest point of every voxel centroid (GM_CFG_NEAREST)."""
         return self._fetch(self._L.gm_get_voxel_nearest, slot, 1, np.int32)
 
+    def voxel_normals(self, slot=0):
+        """normals->at(kIndices[0]) per voxel centroid (tunnel_processing.cpp:247-249): [V,4], needs GM_CFG_NEAREST."""
+        return self._fetch(self._L.gm_get_voxel_normals, slot, 4)
+
     def labels(self, slot=0):
         """Extension: segment label per valid point (0 none, 1 plane, 2 cylinder)."""
         return self._fetch(self._L.gm_get_labels, slot, 1, np.uint8)

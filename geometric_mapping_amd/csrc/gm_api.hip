@@ -312,7 +312,7 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     if ((cf.flags & GM_CFG_NEAREST) && (cf.flags & GM_CFG_VOXEL_GRID)) {
         const uint32_t nq_cap = vd.enabled ? (uint32_t)vd.dim * vd.dim * vd.dim : n;
         launch_nearest(sl.valid4, &sl.ctr->n_valid, n, sl.vox4, &sl.ctr->n_voxels, nq_cap < n ? nq_cap : n, sl.nn_best,
-                       sl.vox_nn, s);
+                       sl.vox_nn, s, sl.vnorm4, sl.vox_nrm4);
     }
     record(ctx, sl, 7);
     launch_frame_finalize(nparts, sl, s);
@@ -422,10 +422,10 @@ gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H)
     GM_HIP(ctx, hipStreamSynchronize(sl.stream));
     hipFree(sl.hyp_plane); hipFree(sl.hyp_cyl); hipFree(sl.band); hipFree(sl.score_partial); hipFree(sl.cnt_plane);
     hipFree(sl.cnt_cyl); hipFree(sl.best_plane); hipFree(sl.best_cyl); hipFree(sl.mom_partial); hipFree(sl.mom_plane);
-    hipFree(sl.mom_cyl); hipFree(sl.nn_best);
+    hipFree(sl.mom_cyl); hipFree(sl.nn_best); hipFree(sl.vox_nrm4);
     // (a failed allocation below must not leave dangling pointers for gm_destroy to free again)
     sl.hyp_plane = sl.hyp_cyl = nullptr; sl.band = nullptr; sl.score_partial = nullptr; sl.cnt_plane = sl.cnt_cyl = nullptr;
-    sl.best_plane = sl.best_cyl = nullptr; sl.mom_partial = sl.mom_plane = sl.mom_cyl = nullptr; sl.nn_best = nullptr;
+    sl.best_plane = sl.best_cyl = nullptr; sl.mom_partial = sl.mom_plane = sl.mom_cyl = nullptr; sl.nn_best = nullptr; sl.vox_nrm4 = nullptr;
     const uint32_t HH = H > sl.ext_H ? H : sl.ext_H;
     sl.ext_H = 0; sl.ext_cap = 0;
     GM_HIP(ctx, dmalloc(sl.hyp_plane, (size_t)HH * 8)); GM_HIP(ctx, dmalloc(sl.hyp_cyl, (size_t)HH * 8));
@@ -436,6 +436,7 @@ gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H)
     GM_HIP(ctx, dmalloc(sl.mom_partial, (size_t)kScatterBlocks * 16));
     GM_HIP(ctx, dmalloc(sl.mom_plane, 16)); GM_HIP(ctx, dmalloc(sl.mom_cyl, 16));
     GM_HIP(ctx, dmalloc(sl.nn_best, sl.cap));
+    GM_HIP(ctx, dmalloc(sl.vox_nrm4, sl.cap));
     GM_HIP(ctx, hipMemset(sl.best_plane, 0xFF, 8));
     GM_HIP(ctx, hipMemset(sl.best_cyl, 0xFF, 8));
     sl.ext_H = HH; sl.ext_cap = sl.cap;
@@ -631,7 +632,7 @@ void gm_destroy(gm_ctx *ctx)
             hipFree(sl.ctr); hipFree(sl.voxp); hipFree(sl.d_out); hipFree(sl.partials); hipFree(sl.vox_table);
             hipFree(sl.hyp_plane); hipFree(sl.hyp_cyl); hipFree(sl.band); hipFree(sl.score_partial);
             hipFree(sl.cnt_plane); hipFree(sl.cnt_cyl); hipFree(sl.best_plane); hipFree(sl.best_cyl);
-            hipFree(sl.mom_partial); hipFree(sl.mom_plane); hipFree(sl.mom_cyl); hipFree(sl.nn_best);
+            hipFree(sl.mom_partial); hipFree(sl.mom_plane); hipFree(sl.mom_cyl); hipFree(sl.nn_best); hipFree(sl.vox_nrm4);
             if (sl.h_out) hipHostFree(sl.h_out);
             for (int k = 0; k <= GM_N_STAGES; ++k) if (sl.ev[k]) hipEventDestroy(sl.ev[k]);
             if (sl.ev_k0) hipEventDestroy(sl.ev_k0);
@@ -868,7 +869,7 @@ gm_status gm_solve_local_frame(const double scatter6[6], float eigenvalues[3], f
 {
     if (!scatter6 || !eigenvalues || !eigenvectors) return GM_ERR_INVALID_ARG;
     double w[3], V[9];
-    jacobi_eig3(scatter6, w, V);
+    eig3_sym_eigen_signs(scatter6, w, V);
     for (int k = 0; k < 3; ++k) eigenvalues[k] = (float)w[k];
     for (int k = 0; k < 9; ++k) eigenvectors[k] = (float)V[k];
     return GM_OK;

@@ -15,14 +15,15 @@ constexpr int kWave = 64;
 struct DevCounters {
     uint32_t n_cropped;   // points surviving the crop box
     uint32_t n_valid;     // points with a finite normal (and owned, when sharded)
-    uint32_t n_tiles;     // query tiles built from the sorted cell keys
-    uint32_t reserved0;
+    uint32_t n_tiles;     // query tiles for the matrix-core kernel (stored from the front of the tile list)
+    uint32_t n_tiles_b;   // query tiles for the all-VALU kernel (sparse / long tiles; stored from the back)
     uint32_t n_voxels;    // occupied voxels
     uint32_t vox_n;       // points entering the voxel grid (= n_valid)
     uint32_t mm[6];       // ordered-uint encodings: min x,y,z then max x,y,z of the valid cloud
     uint32_t scratch_total;
-    uint32_t pad[3];
+    uint32_t pad[5];      // (diagnostic builds count candidate streams here)
 };
+static_assert(sizeof(DevCounters) % 8 == 0, "zero-filled in 8-byte words");
 
 // Voxel-grid parameters derived on the device from the min/max of the cloud
 // (pcl::VoxelGrid::applyFilter: min_b_, div_b_, divb_mul_).
@@ -229,6 +230,119 @@ __host__ __device__ inline void jacobi_eig3(const double a6[6], double w[3], dou
     for (int c = 0; c < 3; ++c) {
         w[c] = a[ord[c]][ord[c]];
         for (int r = 0; r < 3; ++r) V[3 * c + r] = v[r][ord[c]];
+    }
+}
+
+// Symmetric 3x3 eigen-decomposition the way Eigen::SelfAdjointEigenSolver<MatrixXf>::compute reaches it for a
+// dynamic-size matrix (/root/reference src/tunnel_processing.cpp:129): scale by max|a_ij|, one Householder reflection
+// to tridiagonal form, implicit symmetric QR steps with Wilkinson shift and Givens rotations accumulated into the
+// eigenvector matrix, ascending sort -- in the scalar type T with T's convergence thresholds.  The SIGNS of the
+// returned eigenvectors (arbitrary mathematically, visible on /eigenBasisOutput as the arrow directions) depend on the
+// number of QR sweeps, i.e. on the precision the iteration runs in: T = float reproduces the sign pattern of the
+// reference's MatrixXf solve.  a = {xx,xy,xz,yy,yz,zz}; w ascending, V column-major.
+template <class T>
+__host__ __device__ inline void eigen_tridiag_qr3(const T a6[6], T w[3], T V[9])
+{
+    typedef T double_;   // (the body below is written once for both scalar types)
+    double_ scale = 0.0;
+    for (int k = 0; k < 6; ++k) { const double_ t = a6[k] < 0 ? -a6[k] : a6[k]; if (t > scale) scale = t; }
+    if (!(scale > 0.0)) scale = 1.0;
+    const double_ a00 = a6[0] / scale, a10 = a6[1] / scale, a20 = a6[2] / scale, a11 = a6[3] / scale, a21 = a6[4] / scale,
+                 a22 = a6[5] / scale;
+    double_ Q[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    double_ diag[3], sub[2];
+    const double_ tiny = sizeof(T) == 4 ? (T)1.17549435e-38 : (T)2.2250738585072014e-308;
+    if (a20 * a20 <= tiny) {              // column already tridiagonal: no reflection
+        diag[0] = a00; diag[1] = a11; diag[2] = a22; sub[0] = a10; sub[1] = a21;
+    } else {
+        double_ beta = (T)sqrt((double)(a10 * a10 + a20 * a20));
+        if (a10 >= 0) beta = -beta;
+        const double_ ess = a20 / (a10 - beta), tau = (beta - a10) / beta;
+        const double_ v[2] = {1.0, ess};
+        double_ B[2][2] = {{a11, a21}, {a21, a22}};
+        const double_ p0 = tau * (B[0][0] * v[0] + B[0][1] * v[1]), p1 = tau * (B[1][0] * v[0] + B[1][1] * v[1]);
+        const double_ K = -0.5 * tau * (p0 * v[0] + p1 * v[1]);
+        const double_ ww[2] = {p0 + K * v[0], p1 + K * v[1]};
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) B[i][j] -= v[i] * ww[j] + ww[i] * v[j];
+        diag[0] = a00; diag[1] = B[0][0]; diag[2] = B[1][1]; sub[0] = beta; sub[1] = B[1][0];
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) Q[1 + i][1 + j] = (i == j ? 1.0 : 0.0) - tau * v[i] * v[j];
+    }
+    int end = 2, start = 0, iter = 0;
+    const double_ prec = sizeof(T) == 4 ? (T)(2.0 * 1.1920928955078125e-7) : (T)(2.0 * 2.220446049250313e-16);
+    while (end > 0) {
+        for (int i = start; i < end; ++i) {
+            const double_ s = sub[i] < 0 ? -sub[i] : sub[i];
+            const double_ d = (diag[i] < 0 ? -diag[i] : diag[i]) + (diag[i + 1] < 0 ? -diag[i + 1] : diag[i + 1]);
+            if (s <= d * prec || s <= tiny) sub[i] = 0.0;
+        }
+        while (end > 0 && sub[end - 1] == 0.0) --end;
+        if (end <= 0) break;
+        if (++iter > 90) break;
+        start = end - 1;
+        while (start > 0 && sub[start - 1] != 0.0) --start;
+        const double_ td = (diag[end - 1] - diag[end]) * 0.5, e = sub[end - 1];
+        double_ mu = diag[end];
+        if (td == 0.0) mu -= (e < 0 ? -e : e);
+        else {
+            const double_ h = (T)sqrt((double)(td * td + e * e));
+            mu -= (e * e) / (td + (td > 0 ? h : -h));
+        }
+        double_ x = diag[start] - mu, z = sub[start];
+        for (int k = start; k < end; ++k) {
+            double_ c, s;   // Givens rotation taking (x, z) to (r, 0), Eigen's JacobiRotation::makeGivens conventions
+            if (z == 0.0) { c = x < 0 ? -1.0 : 1.0; s = 0.0; }
+            else if (x == 0.0) { c = 0.0; s = z < 0 ? 1.0 : -1.0; }
+            else if ((x < 0 ? -x : x) > (z < 0 ? -z : z)) {
+                const double_ t = z / x; double_ u = (T)sqrt((double)((T)1 + t * t));
+                if (x < 0) u = -u;
+                c = 1.0 / u; s = -t * c;
+            } else {
+                const double_ t = x / z; double_ u = (T)sqrt((double)((T)1 + t * t));
+                if (z < 0) u = -u;
+                s = -1.0 / u; c = -t * s;
+            }
+            const double_ sdk = s * diag[k] + c * sub[k], dkp1 = s * sub[k] + c * diag[k + 1];
+            diag[k] = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
+            diag[k + 1] = s * sdk + c * dkp1;
+            sub[k] = c * sdk - s * dkp1;
+            if (k > start) sub[k - 1] = c * sub[k - 1] - s * z;
+            x = sub[k];
+            if (k < end - 1) { z = -s * sub[k + 1]; sub[k + 1] = c * sub[k + 1]; }
+            for (int r = 0; r < 3; ++r) {
+                const double_ xi = Q[r][k], yi = Q[r][k + 1];
+                Q[r][k] = c * xi - s * yi;
+                Q[r][k + 1] = s * xi + c * yi;
+            }
+        }
+    }
+    for (int i = 0; i < 2; ++i) {          // ascending selection sort, columns follow
+        int k = i;
+        for (int j = i + 1; j < 3; ++j) if (diag[j] < diag[k]) k = j;
+        if (k != i) {
+            const double_ t = diag[i]; diag[i] = diag[k]; diag[k] = t;
+            for (int r = 0; r < 3; ++r) { const double_ u = Q[r][i]; Q[r][i] = Q[r][k]; Q[r][k] = u; }
+        }
+    }
+    for (int c = 0; c < 3; ++c) {
+        w[c] = diag[c] * scale;
+        for (int r = 0; r < 3; ++r) V[3 * c + r] = Q[r][c];
+    }
+}
+
+
+// Accurate eigenpairs (fp64 Jacobi) with the column signs of the reference's float solve (above, T = float).
+__host__ __device__ inline void eig3_sym_eigen_signs(const double a6[6], double w[3], double V[9])
+{
+    jacobi_eig3(a6, w, V);
+    float af[6], wf[3], Vf[9];
+    for (int k = 0; k < 6; ++k) af[k] = (float)a6[k];
+    eigen_tridiag_qr3<float>(af, wf, Vf);
+    for (int c = 0; c < 3; ++c) {
+        const double d = V[3 * c] * (double)Vf[3 * c] + V[3 * c + 1] * (double)Vf[3 * c + 1] + V[3 * c + 2] * (double)Vf[3 * c + 2];
+        if (d < 0.0)
+            for (int r = 0; r < 3; ++r) V[3 * c + r] = -V[3 * c + r];
     }
 }
 

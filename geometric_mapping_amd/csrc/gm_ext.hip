@@ -248,6 +248,16 @@ gm_status gm_get_voxel_nearest(gm_ctx *ctx, uint32_t slot, int32_t *idx, uint32_
     return fetch_bytes(ctx, sl, sl.vox_nn, sl.last.n_voxels, 4, idx, capacity, n_out);
 }
 
+gm_status gm_get_voxel_normals(gm_ctx *ctx, uint32_t slot, float *nxyzc, uint32_t capacity, uint32_t *n_out)
+{
+    gm_status st = gm_check_slot(ctx, slot);
+    if (st != GM_OK) return st;
+    if ((ctx->cfg.flags & (GM_CFG_NEAREST | GM_CFG_VOXEL_GRID)) != (GM_CFG_NEAREST | GM_CFG_VOXEL_GRID))
+        return gm_fail(ctx, GM_ERR_NOT_READY, "context created without GM_CFG_NEAREST | GM_CFG_VOXEL_GRID");
+    Slot &sl = ctx->slots[slot];
+    return fetch_bytes(ctx, sl, sl.vox_nrm4, sl.last.n_voxels, 16, nxyzc, capacity, n_out);
+}
+
 gm_status gm_get_labels(gm_ctx *ctx, uint32_t slot, uint8_t *labels, uint32_t capacity, uint32_t *n_out)
 {
     gm_status st = gm_check_slot(ctx, slot);

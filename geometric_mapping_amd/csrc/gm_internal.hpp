@@ -70,6 +70,7 @@ struct Slot {
     double *mom_partial = nullptr;                    // [kScatterBlocks][16]
     double *mom_plane = nullptr, *mom_cyl = nullptr;  // [16]
     unsigned long long *nn_best = nullptr;            // [cap]
+    float4 *vox_nrm4 = nullptr;                       // [cap] normal of each voxel centroid's nearest point (GM_CFG_NEAREST)
     // state
     bool submitted = false, complete = false;
     bool vox_sort_path = false;  // this frame's voxels came from the sort path (may report passthrough)
@@ -149,7 +150,8 @@ void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, con
                          const double *partial32, uint32_t mom_rows, hipStream_t s);
 // k_nearest.hip
 void launch_nearest(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, const float4 *queries,
-                    const uint32_t *nq_ptr, uint32_t nq_cap, unsigned long long *best, int32_t *idx, hipStream_t s);
+                    const uint32_t *nq_ptr, uint32_t nq_cap, unsigned long long *best, int32_t *idx, hipStream_t s,
+                    const float4 *attr = nullptr, float4 *attr_out = nullptr);  // attr_out[q] = attr[idx[q]]
 
 // gm_api.hip helpers shared with gm_ext.hip
 gm_status gm_fail(gm_ctx *ctx, gm_status st, const char *msg);

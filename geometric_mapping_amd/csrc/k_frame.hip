@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_frame_finalize(const double *__restrict
     if (threadIdx.x == 0) {
         double M[6], w[3], V[9];
         for (int k = 0; k < 6; ++k) { M[k] = red[0][k]; out->scatter[k] = M[k]; }
-        jacobi_eig3(M, w, V);
+        eig3_sym_eigen_signs(M, w, V);   // fp64 Jacobi pairs, column signs of Eigen's float tridiagonal-QR solve
         for (int k = 0; k < 3; ++k) out->evals[k] = (float)w[k];
         for (int k = 0; k < 9; ++k) out->evecs[k] = (float)V[k];
         if (ctr) out->ctr = *ctr;

@@ -61,17 +61,25 @@ __global__ __launch_bounds__(256) void k_nn_scan(const float4 *__restrict__ pts,
 
 __global__ __launch_bounds__(256) void k_nn_unpack(const unsigned long long *__restrict__ best,
                                                    const uint32_t *__restrict__ nq_ptr, uint32_t nq_host,
-                                                   int32_t *__restrict__ idx)
+                                                   int32_t *__restrict__ idx, const float4 *__restrict__ attr,
+                                                   float4 *__restrict__ attr_out)
 {
     const uint32_t nq = nq_ptr ? *nq_ptr : nq_host;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) {
         const unsigned long long k = best[i];
-        idx[i] = (k == 0xFFFFFFFFFFFFFFFFull) ? -1 : (int32_t)(uint32_t)(k & 0xFFFFFFFFull);
+        const int32_t j = (k == 0xFFFFFFFFFFFFFFFFull) ? -1 : (int32_t)(uint32_t)(k & 0xFFFFFFFFull);
+        idx[i] = j;
+        // normals->at(kIndices[0]) of the marker loop (src/tunnel_processing.cpp:247-249), gathered where the index is made
+        if (attr_out) {
+            const float nanv = __builtin_nanf("");
+            attr_out[i] = j >= 0 ? attr[j] : make_float4(nanv, nanv, nanv, nanv);
+        }
     }
 }
 
 void launch_nearest(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, const float4 *queries,
-                    const uint32_t *nq_ptr, uint32_t nq_cap, unsigned long long *best, int32_t *idx, hipStream_t s)
+                    const uint32_t *nq_ptr, uint32_t nq_cap, unsigned long long *best, int32_t *idx, hipStream_t s,
+                    const float4 *attr, float4 *attr_out)
 {
     if (nq_cap == 0) return;
     uint32_t gq = (nq_cap + 255) / 256;
@@ -82,7 +90,7 @@ void launch_nearest(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, co
         hipLaunchKernelGGL(k_nn_scan, dim3(gq, chunks), dim3(256), 0, s, pts, n_ptr, n_cap, queries, nq_ptr, nq_cap,
                            best);
     }
-    hipLaunchKernelGGL(k_nn_unpack, dim3(gi), dim3(256), 0, s, (const unsigned long long *)best, nq_ptr, nq_cap, idx);
+    hipLaunchKernelGGL(k_nn_unpack, dim3(gi), dim3(256), 0, s, (const unsigned long long *)best, nq_ptr, nq_cap, idx, attr, attr_out);
 }
 
 }  // namespace gm

@@ -107,13 +107,18 @@ __global__ __launch_bounds__(256) void k_gather_sorted(const float4 *__restrict_
 // full tiles: ~90 % lane fill) and a 64-chunk that spans more than `span` cell steps (sparse
 // rows) is cut again at aligned (span+1)-cell groups, which bounds the candidate count of a
 // tile: without the bound a sparse row yields tiles 20x the mean that the whole grid waits for.
+// Two lists come out: tiles whose 64-chunk is short (<= mx_span fine cells: dense rows) go to the matrix-core kernel
+// (front of `tiles`, count n_tiles); long / span-cut tiles of sparse rows go to the all-VALU kernel (back of `tiles`,
+// count n_tiles_b), whose offsets-from-the-own-query accumulation keeps its precision however far a tile stretches
+// and which has no per-tile feature staging to amortise over a handful of candidates.
 __global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict__ skeys,
                                                       DevCounters *__restrict__ ctr, uint32_t nx, uint32_t span,
+                                                      uint32_t mx_span, uint32_t mx_mode /* 0 none, 1 by span, 2 all */,
                                                       const uint2 *__restrict__ row_bounds,
                                                       uint2 *__restrict__ tiles, uint32_t tiles_cap)
 {
-    __shared__ uint32_t wtot[1024 / kWave];
-    __shared__ uint32_t block_base;
+    __shared__ uint32_t wtot[2][1024 / kWave];
+    __shared__ uint32_t block_base[2];
     const uint32_t n = ctr->n_cropped;
     const uint32_t s = blockIdx.x * 1024u + threadIdx.x;
     if (blockIdx.x * 1024u >= n) return;  // uniform per block
@@ -121,13 +126,16 @@ __global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict
     // a point starts a tile iff it starts a 64-chunk of its x-row, or its chunk is "sparse"
     // (spans more than `span` cell steps) and it is the first point of an aligned cell group
     uint32_t cnt = 0, tend = 0;
+    bool to_mx = false;
     if (s < n) {
         const uint32_t key = skeys[s];
         const uint32_t row = key / nx;
         const uint2 rb = row_bounds[row];  // written by k_gather_sorted
         const uint32_t cstart = rb.x + ((s - rb.x) / (uint32_t)kTileQ) * (uint32_t)kTileQ;
         const uint32_t cend = (cstart + kTileQ < rb.y) ? cstart + kTileQ : rb.y;
-        const bool sparse = skeys[cend - 1] - skeys[cstart] > span;  // same row: key difference = cell steps
+        const uint32_t extent = skeys[cend - 1] - skeys[cstart];     // same row: key difference = cell steps
+        const bool sparse = extent > span;
+        to_mx = mx_mode == 2u || (mx_mode == 1u && extent <= mx_span);
         const uint32_t group = span + 1u;
         const uint32_t my_group = (key - row * nx) / group;
         if (s == cstart) cnt = 1;
@@ -146,21 +154,26 @@ __global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict
             }
         }
     }
-    // block-wide exclusive prefix of the flags, ONE atomic per block for the base
-    const uint32_t inc = wave_inclusive_scan(cnt);
-    if (lane_id() == kWave - 1) wtot[w] = inc;
+    // block-wide exclusive prefix of the flags of each list, ONE atomic per block and list for the base
+    const uint32_t ca = (cnt && to_mx) ? 1u : 0u, cb = (cnt && !to_mx) ? 1u : 0u;
+    const uint32_t inca = wave_inclusive_scan(ca), incb = wave_inclusive_scan(cb);
+    if (lane_id() == kWave - 1) { wtot[0][w] = inca; wtot[1][w] = incb; }
     __syncthreads();
-    uint32_t woff = 0, total = 0;
+    uint32_t woffa = 0, tota = 0, woffb = 0, totb = 0;
 #pragma unroll
     for (int k = 0; k < 1024 / kWave; ++k) {
-        const uint32_t c = wtot[k];
-        if (k < w) woff += c;
-        total += c;
+        const uint32_t c0 = wtot[0][k], c1 = wtot[1][k];
+        if (k < w) { woffa += c0; woffb += c1; }
+        tota += c0; totb += c1;
     }
-    if (threadIdx.x == 0) block_base = total ? atomicAdd(&ctr->n_tiles, total) : 0u;
+    if (threadIdx.x == 0) {
+        block_base[0] = tota ? atomicAdd(&ctr->n_tiles, tota) : 0u;
+        block_base[1] = totb ? atomicAdd(&ctr->n_tiles_b, totb) : 0u;
+    }
     __syncthreads();
-    const uint32_t t_out = block_base + woff + inc - cnt;
-    if (cnt && t_out < tiles_cap) tiles[t_out] = make_uint2(s, tend - s);  // first query, number of queries
+    // (the two lists grow towards each other and together never hold more than tiles_cap entries: max_tiles())
+    if (ca) { const uint32_t t_out = block_base[0] + woffa + inca - 1u; if (t_out < tiles_cap) tiles[t_out] = make_uint2(s, tend - s); }
+    if (cb) { const uint32_t t_out = block_base[1] + woffb + incb - 1u; if (t_out < tiles_cap) tiles[tiles_cap - 1u - t_out] = make_uint2(s, tend - s); }
 }
 
 // ---- smallest eigenpair of a symmetric PSD 3x3, fp64 ----------------------------
@@ -221,51 +234,126 @@ __device__ __forceinline__ bool smallest_eigpair(const double c[6], double &lam,
     return true;
 }
 
-// ---- the neighbourhood kernel ----------------------------------------------------
-__global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict__ spts4,
-                                                        const uint32_t *__restrict__ skeys,
-                                                        const uint2 *__restrict__ tiles,
-                                                        DevCounters *__restrict__ ctr, GridParams g,
-                                                        uint32_t tiles_cap, const uint2 *__restrict__ row_bounds,
-                                                        float4 *__restrict__ normals4,
-                                                        int32_t *__restrict__ counts, VoxDense vd,
-                                                        VoxCell *__restrict__ vox_table)
+// ---- per-query epilogue shared by both formulations of the neighbourhood kernel ----
+// mom = {n, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz}: moments of the neighbours' offsets from ANY fixed point (the
+// covariance does not depend on it).  NormalEstimation::computePointNormal + flipNormalTowardsViewpoint(p, 0,0,0).
+// Returns whether the point enters the voxel grid (finite normal and owned by this rank's slab).
+__device__ __forceinline__ bool emit_normal(bool active, const float4 q, const double mom[10], const VoxDense &vd,
+                                            float4 *__restrict__ normals4, int32_t *__restrict__ counts, uint32_t qn,
+                                            unsigned long long stat_t0)
 {
+    bool vox_ok = false;
+    const int cnt = (int)mom[0];
+    if (active) {
+        const uint32_t dst = __float_as_uint(q.w);
+        float4 out = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+        if (cnt >= 3) {
+            const double inv_n = 1.0 / (double)cnt;
+            const double mx = mom[1] * inv_n, my = mom[2] * inv_n, mz = mom[3] * inv_n;
+            double c[6];
+            c[0] = mom[4] * inv_n - mx * mx; c[1] = mom[5] * inv_n - mx * my; c[2] = mom[6] * inv_n - mx * mz;
+            c[3] = mom[7] * inv_n - my * my; c[4] = mom[8] * inv_n - my * mz; c[5] = mom[9] * inv_n - mz * mz;
+            double lam, nv[3];
+            if (smallest_eigpair(c, lam, nv)) {
+                const double trc = c[0] + c[3] + c[5];
+                const double curv = (trc != 0.0) ? fabs(lam / trc) : 0.0;
+                const double ct = -((double)q.x * nv[0] + (double)q.y * nv[1] + (double)q.z * nv[2]);
+                const double sgn = (ct < 0.0) ? -1.0 : 1.0;
+                out = make_float4((float)(sgn * nv[0]), (float)(sgn * nv[1]), (float)(sgn * nv[2]), (float)curv);
+                vox_ok = finite3(out.x, out.y, out.z) && q.x >= vd.own_lo && q.x < vd.own_hi;
+            }
+        }
+        normals4[dst] = out;
+        if (counts) counts[dst] = cnt;
+#ifdef GM_NORMALS_TIMELINE  // diagnostic build (tools/tile_timeline.py): lanes 0 / 1 of a tile report its end tick / duration
+        {
+            const unsigned long long t1 = wall_clock64();
+            const int lane = lane_id();
+            if (counts && qn >= 2 && lane == 0) counts[dst] = -(int)((t1 & 0x1FFFFFFFull) | 0x20000000ull);  // end tick, bit 29 set
+            if (counts && qn >= 2 && lane == 1) counts[dst] = -(int)((t1 - stat_t0) & 0xFFFFFull) - 1;        // duration < 2^20 ticks
+        }
+#endif
+    }
+    return vox_ok;
+}
+
+// ---- VoxelGrid fast path: points of a tile are spatial neighbours, so they fall into one to three voxels;
+// reduce by voxel inside the wave, then one set of integer atomics per (wave, voxel).
+// (pcl::VoxelGrid, src/tunnel_processing.cpp:217-220)
+__device__ __forceinline__ void voxel_sums(bool vox_ok, const float4 q, const VoxDense &vd, VoxCell *__restrict__ vox_table)
+{
+    const int lane = lane_id();
+    uint32_t vkey = 0;
+    unsigned long long fx = 0, fy = 0, fz = 0;
+    if (vox_ok) {
+        const int ix = (int)floorf(q.x * vd.inv_leaf) - vd.i_lo;
+        const int iy = (int)floorf(q.y * vd.inv_leaf) - vd.i_lo;
+        const int iz = (int)floorf(q.z * vd.inv_leaf) - vd.i_lo;
+        vkey = (uint32_t)((iz * vd.dim + iy) * vd.dim + ix);
+        fx = (unsigned long long)(((double)q.x - (double)vd.lo) * vd.scale + 0.5);
+        fy = (unsigned long long)(((double)q.y - (double)vd.lo) * vd.scale + 0.5);
+        fz = (unsigned long long)(((double)q.z - (double)vd.lo) * vd.scale + 0.5);
+    }
+    uint64_t remaining = __ballot(vox_ok);
+    while (remaining) {  // wave-uniform loop
+        const int leader = (int)__builtin_ctzll(remaining);
+        const uint32_t k = __shfl(vkey, leader, kWave);
+        const bool mine = vox_ok && vkey == k;
+        const uint64_t same = __ballot(mine);
+        const unsigned long long ax = wave_sum(mine ? fx : 0ull);
+        const unsigned long long ay = wave_sum(mine ? fy : 0ull);
+        const unsigned long long az = wave_sum(mine ? fz : 0ull);
+        if (lane == leader) {
+            VoxCell *cell = vox_table + k;
+            atomicAdd(&cell->sx, ax);
+            atomicAdd(&cell->sy, ay);
+            atomicAdd(&cell->sz, az);
+            atomicAdd(&cell->cnt, (uint32_t)__popcll(same));
+        }
+        remaining &= ~same;
+    }
+}
+
+// Everything the tile bodies need (one struct: the kernel takes it by value)
+struct NormalsArgs {
+    const float4 *__restrict__ spts4;
+    const uint32_t *__restrict__ skeys;
+    const uint2 *__restrict__ tiles;
+    DevCounters *__restrict__ ctr;
+    GridParams g;
+    uint32_t tiles_cap;
+    const uint2 *__restrict__ row_bounds;
+    float4 *__restrict__ normals4;
+    int32_t *__restrict__ counts;
+    VoxDense vd;
+    VoxCell *__restrict__ vox_table;
+};
+
+// ---- one tile, all-VALU formulation ------------------------------------------------
+// (long / sparse tiles: the list k_build_tiles stores from the back of `tiles`)
+constexpr int kValuLdsBytes = kNrWaves * 3 * (kWinCap + kWinPad) * 4 + kNrWaves * 10 * kWave * 8;
+__device__ __forceinline__ void normals_tile_valu(const NormalsArgs &A, unsigned char *lds, const uint2 tile)
+{
+    const float4 *__restrict__ spts4 = A.spts4;
+    const uint32_t *__restrict__ skeys = A.skeys;
+    DevCounters *__restrict__ ctr = A.ctr;
+    const GridParams &g = A.g;
+    const uint2 *__restrict__ row_bounds = A.row_bounds;
+    float4 *__restrict__ normals4 = A.normals4;
+    int32_t *__restrict__ counts = A.counts;
+    const VoxDense &vd = A.vd;
+    VoxCell *__restrict__ vox_table = A.vox_table;
+    (void)ctr;
     // candidate window, one per wave, SoA so that one broadcast ds_read_b128 feeds
-    // the x (or y, z) of FOUR candidates to every lane
-    __shared__ __attribute__((aligned(16))) float win[kNrWaves][3][kWinCap + kWinPad];
-    __shared__ double tot[kNrWaves][10][kWave];  // per-lane fp64 moment totals of the current tile
+    // the x (or y, z) of FOUR candidates to every lane; then the per-lane fp64 moment totals of the tile
+    typedef float WinT[3][kWinCap + kWinPad];
+    typedef double TotT[10][kWave];
+    WinT *win = reinterpret_cast<WinT *>(lds);
+    TotT *tot = reinterpret_cast<TotT *>(lds + sizeof(WinT) * kNrWaves);
     const int lane = lane_id();
     const int w = threadIdx.x / kWave;
     const uint32_t n = ctr->n_cropped;
-    uint32_t ntiles = ctr->n_tiles;
-    if (ntiles > tiles_cap) ntiles = tiles_cap;
-
-    // Tiles are assigned by wave id (grid-stride; with the default grid every wave gets at most one tile and
-    // its block retires right after).  The hardware block scheduler does the load balancing, and because no
-    // block is long-lived the kernels of other frames in flight get wave slots as blocks retire -- a
-    // persistent work-queue grid measured 8 % slower alone and 4 % slower with three frames in flight.
-    // XCD-aware tile mapping.  The dispatcher deals consecutive blocks round-robin to the 8 XCDs, each with its own
-    // L2; the tile list is in (nearly) sorted order, so neighbouring tiles share candidate rows.  With one wave per
-    // tile the blocks that have work (the first ceil(ntiles / 4)) are re-labelled bijectively so that runs of
-    // consecutive tiles land on ONE XCD: a sorted row is then fetched into one L2 instead of all eight.
-    uint32_t vblock = blockIdx.x;
-    const uint32_t nblk = (ntiles + kNrWaves - 1) / kNrWaves;
-    if (gridDim.x >= nblk && vd.xcd_chunk) {
-        if (blockIdx.x >= nblk) return;  // uniform per block: no tile for this block
-        // chunks of xcd_chunk consecutive blocks (4 tiles each) go to one XCD, chunks are dealt round-robin: locality
-        // inside a chunk, balance across the XCDs; the tail that does not fill 8 chunks keeps the plain mapping
-        const uint32_t cb = vd.xcd_chunk, full = nblk / (8u * cb) * (8u * cb);
-        if (blockIdx.x < full) {
-            const uint32_t xcd = blockIdx.x % 8u, slot = blockIdx.x / 8u;
-            vblock = ((slot / cb) * 8u + xcd) * cb + slot % cb;
-        }
-    }
-    const uint32_t wave_id = vblock * kNrWaves + (uint32_t)w, n_waves = gridDim.x * kNrWaves;
-    for (uint32_t iter = 0;; ++iter) {
-        const uint32_t t = wave_id + iter * n_waves;
-        if (t >= ntiles) break;  // every wave reaches this: the tile list is final before the launch
-        const uint2 tile = tiles[t];
+    {
         const uint32_t qs = tile.x, qn = tile.y;  // first query (sorted position), number of queries (1..64)
 #ifdef GM_NORMALS_TIMELINE
         const unsigned long long stat_t0 = wall_clock64();
@@ -289,7 +377,7 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
                 normals4[__float_as_uint(q.w)] = make_float4(nanv, nanv, nanv, nanv);
                 if (counts) counts[__float_as_uint(q.w)] = 0;
             }
-            continue;
+            return;
         }
 
         // ---- candidate windows.  The 3x3 neighbouring x-rows are x-sorted runs of the sorted cloud.  The
@@ -408,7 +496,7 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
                     atomicAdd(&ctr->pad[0], (uint32_t)(((iters + 1) & ~1) * 4));  // wave-candidates streamed
                     atomicAdd(&ctr->pad[1], sum_len);                              // sum of the 4 group windows
                     atomicAdd(&ctr->pad[2], clen);                                 // candidates staged
-                    atomicAdd(&ctr->reserved0, 1u);                                // chunks
+                    atomicAdd(&ctr->pad[3], 1u);                                   // chunks
                 }
             }
 #endif
@@ -466,74 +554,317 @@ __global__ __launch_bounds__(kNrThreads) void k_normals(const float4 *__restrict
         fold();
         const double Sn = T[0 * kWave], Sx = T[1 * kWave], Sy = T[2 * kWave], Sz = T[3 * kWave], Sxx = T[4 * kWave],
                      Sxy = T[5 * kWave], Sxz = T[6 * kWave], Syy = T[7 * kWave], Syz = T[8 * kWave], Szz = T[9 * kWave];
-        const int cnt = (int)Sn;
-
-        bool vox_ok = false;
-        if (active) {
-            const uint32_t dst = __float_as_uint(q.w);
-            float4 out = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
-            if (cnt >= 3) {  // NormalEstimation::computePointNormal
-                const double inv_n = 1.0 / (double)cnt;
-                const double mx = Sx * inv_n, my = Sy * inv_n, mz = Sz * inv_n;
-                double c[6];
-                c[0] = Sxx * inv_n - mx * mx; c[1] = Sxy * inv_n - mx * my; c[2] = Sxz * inv_n - mx * mz;
-                c[3] = Syy * inv_n - my * my; c[4] = Syz * inv_n - my * mz; c[5] = Szz * inv_n - mz * mz;
-                double lam, nv[3];
-                if (smallest_eigpair(c, lam, nv)) {
-                    const double trc = c[0] + c[3] + c[5];
-                    const double curv = (trc != 0.0) ? fabs(lam / trc) : 0.0;
-                    // flipNormalTowardsViewpoint(p, 0,0,0)
-                    const double ct = -((double)q.x * nv[0] + (double)q.y * nv[1] + (double)q.z * nv[2]);
-                    const double sgn = (ct < 0.0) ? -1.0 : 1.0;
-                    out = make_float4((float)(sgn * nv[0]), (float)(sgn * nv[1]), (float)(sgn * nv[2]), (float)curv);
-                    vox_ok = finite3(out.x, out.y, out.z) && q.x >= vd.own_lo && q.x < vd.own_hi;
-                }
-            }
-            normals4[dst] = out;
-            if (counts) counts[dst] = cnt;
-#ifdef GM_NORMALS_TIMELINE  // diagnostic build (tools/tile_timeline.py): lanes 0 / 1 of a tile report its end tick / duration
-            {
-                const unsigned long long t1 = wall_clock64();
-                if (counts && qn >= 2 && lane == 0) counts[dst] = -(int)((t1 & 0x1FFFFFFFull) | 0x20000000ull);  // end tick, bit 29 set
-                if (counts && qn >= 2 && lane == 1) counts[dst] = -(int)((t1 - stat_t0) & 0xFFFFFull) - 1;        // duration < 2^20 ticks
-            }
+        const double mom[10] = {Sn, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz};
+#ifdef GM_NORMALS_TIMELINE
+        const bool vox_ok = emit_normal(active, q, mom, vd, normals4, counts, qn, stat_t0);
+#else
+        const bool vox_ok = emit_normal(active, q, mom, vd, normals4, counts, qn, 0ull);
 #endif
-        }
+        if (vd.enabled) voxel_sums(vox_ok, q, vd, vox_table);
+    }
+}
 
-        // ---- VoxelGrid fast path: points of a tile are spatial neighbours, so they fall
-        // into one to three voxels; reduce by voxel inside the wave, then one set of
-        // integer atomics per (wave, voxel).  (pcl::VoxelGrid, src/tunnel_processing.cpp:217-220)
-        if (vd.enabled) {
-            uint32_t vkey = 0;
-            unsigned long long fx = 0, fy = 0, fz = 0;
-            if (vox_ok) {
-                const int ix = (int)floorf(q.x * vd.inv_leaf) - vd.i_lo;
-                const int iy = (int)floorf(q.y * vd.inv_leaf) - vd.i_lo;
-                const int iz = (int)floorf(q.z * vd.inv_leaf) - vd.i_lo;
-                vkey = (uint32_t)((iz * vd.dim + iy) * vd.dim + ix);
-                fx = (unsigned long long)(((double)q.x - (double)vd.lo) * vd.scale + 0.5);
-                fy = (unsigned long long)(((double)q.y - (double)vd.lo) * vd.scale + 0.5);
-                fz = (unsigned long long)(((double)q.z - (double)vd.lo) * vd.scale + 0.5);
+// ---- the neighbourhood kernel, matrix-core formulation ---------------------------
+// Same tiles, same grid, same neighbour predicate -- but the ten moments of a neighbourhood are a matrix product:
+//     S[feature f][query q] = sum over candidates c of  G[f][c] * W[c][q],   W[c][q] = 1 if |c - q|^2 < r^2 else 0,
+// with G the monomials {1, u, u u^T} of the candidate's offset u = c - o from ONE origin o per tile (the covariance
+// does not depend on the origin; |u| < ~2r, so no cancellation).  W is exact in bf16; every fp32 feature value is cut
+// into three bf16 terms (8 + 8 + 8 mantissa bits: the cut is exact), which makes 1 + 9 x 3 = 28 rows of a
+// 32-row A operand, and v_mfma_f32_32x32x16_bf16 accumulates them in fp32 (measured on gfx950,
+// tools/microbench/mfma_probe.hip: no truncation bias, error of a 640-term sum below that of an fp32 fma chain).
+// The VALU keeps only the predicate (9 packed operations per two pairs, exactly FLANN's rounding) and one v_perm to
+// pack two weights: 10 operations per two pairs instead of 21, the twelve moment operations run on the matrix pipe.
+//   * a tile is two groups of 32 queries; in a group's loop lane l stands for query (l & 31) and candidate octet
+//     (l >> 5): per MFMA a lane tests its query against 8 candidates and hands the 8 weights over as its B fragment;
+//   * the candidates of a row range are staged once per tile: x, y, z as fp32 SoA (predicate) and the 32 feature
+//     rows as [octet][row][8 candidates] bf16, 464 B per octet, so a lane's A fragment is one ds_read_b128;
+//   * D comes out with the query on the lane: lanes l and l ^ 32 hold complementary feature rows of one query.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef GM_MXCHUNK
+#define GM_MXCHUNK 128
+#endif
+#ifndef GM_MX_WAVES
+#define GM_MX_WAVES 4   // waves per SIMD the register allocation aims for (with 128-candidate chunks LDS allows four blocks per CU)
+#endif
+constexpr int kMxChunk = GM_MXCHUNK;      // candidates staged per chunk of a row range (multiple of 16)
+constexpr int kMxPad = 16;                // far-away padding behind a chunk (the last 16-candidate block of a group)
+#ifndef GM_MXSPAN
+#define GM_MXSPAN 2
+#endif
+constexpr int kMxSpan = GM_MXSPAN;        // longest tile (in coarse cells) the matrix-core kernel takes; longer ones go to the VALU kernel
+constexpr int kMxGroups = 2;              // query groups of a tile: 32 queries each (the N of the 32x32x16 MFMA)
+constexpr int kMxGroupLanes = kWave / kMxGroups;
+constexpr int kMxOctets = (kMxChunk + kMxPad) / 8;
+constexpr int kMxRows = 28;               // feature rows per octet: 1 + 9 x 3.  The A operand's rows 28..31 read the pad row and the
+                                          // next octet's first rows: whatever is there only reaches result rows nobody reads
+constexpr int kMxOctetWords = 29 * 4;     // 464 B per octet: 116 dwords = 20 mod 32 banks, so the staging stores of the 16
+                                          // octets a wave writes at once spread over all banks (448 B would be 8-way conflicts)
+static_assert(kMxChunk % 16 == 0, "chunks are cut into 16-candidate MFMA steps");
+
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t hi_src, uint32_t lo_src)
+{
+    return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u);  // (lo_src >> 16) | (hi_src & 0xFFFF0000)
+}
+
+// per wave: the candidate window as fp32 SoA, then the feature rows [octet][29 rows][8 bf16] (+ the last octet's
+// over-read).  The prefetch of a group's last step reads 16 slots past its array: x into y, y into z, z into the
+// feature rows -- inside this struct, values never used.
+struct MxWaveLds {
+    float w[3][kMxChunk + kMxPad];
+    uint32_t f[kMxOctets * kMxOctetWords + 16];
+};
+constexpr int kMxLdsBytes = (int)sizeof(MxWaveLds) * kNrWaves;
+
+__device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned char *lds, const uint2 tile)
+{
+    const float4 *__restrict__ spts4 = A.spts4;
+    const uint32_t *__restrict__ skeys = A.skeys;
+    DevCounters *__restrict__ ctr = A.ctr;
+    const GridParams &g = A.g;
+    const uint2 *__restrict__ row_bounds = A.row_bounds;
+    float4 *__restrict__ normals4 = A.normals4;
+    int32_t *__restrict__ counts = A.counts;
+    const VoxDense &vd = A.vd;
+    VoxCell *__restrict__ vox_table = A.vox_table;
+    (void)ctr;
+    MxWaveLds *mxl = reinterpret_cast<MxWaveLds *>(lds);
+    const int lane = lane_id();
+    const int w = threadIdx.x / kWave;
+    const uint32_t n = ctr->n_cropped;
+    float *wx = &mxl[w].w[0][0], *wy = &mxl[w].w[1][0], *wz = &mxl[w].w[2][0];
+    uint32_t *feat = &mxl[w].f[0];
+    const int qsel = lane & 31, half = lane >> 5;
+    {
+        const uint32_t qs = tile.x, qn = tile.y;
+#ifdef GM_NORMALS_TIMELINE
+        const unsigned long long stat_t0 = wall_clock64();
+#else
+        const unsigned long long stat_t0 = 0ull;
+#endif
+        const bool active = (uint32_t)lane < qn;
+        const uint32_t qidx = qs + (active ? (uint32_t)lane : qn - 1u);
+        const float4 q = spts4[qidx];
+        const uint32_t kl = skeys[qidx];
+        const uint32_t ka = __builtin_amdgcn_readfirstlane(kl);
+        const uint32_t row = ka / (uint32_t)g.nx;
+        const int cy = (int)(row % (uint32_t)g.ny), cz = (int)(row / (uint32_t)g.ny);
+        const int fxl = (int)(kl - row * (uint32_t)g.nx);
+        if (__ballot(active && q.x >= vd.own_lo && q.x < vd.own_hi) == 0) {  // halo-only tile (slab sharding)
+            if (active) {
+                const float nanv = __builtin_nanf("");
+                normals4[__float_as_uint(q.w)] = make_float4(nanv, nanv, nanv, nanv);
+                if (counts) counts[__float_as_uint(q.w)] = 0;
             }
-            uint64_t remaining = __ballot(vox_ok);
-            while (remaining) {  // wave-uniform loop
-                const int leader = (int)__builtin_ctzll(remaining);
-                const uint32_t k = __shfl(vkey, leader, kWave);
-                const bool mine = vox_ok && vkey == k;
-                const uint64_t same = __ballot(mine);
-                const unsigned long long ax = wave_sum(mine ? fx : 0ull);
-                const unsigned long long ay = wave_sum(mine ? fy : 0ull);
-                const unsigned long long az = wave_sum(mine ? fz : 0ull);
-                if (lane == leader) {
-                    VoxCell *cell = vox_table + k;
-                    atomicAdd(&cell->sx, ax);
-                    atomicAdd(&cell->sy, ay);
-                    atomicAdd(&cell->sz, az);
-                    atomicAdd(&cell->cnt, (uint32_t)__popcll(same));
+            return;
+        }
+        // ---- candidate windows: lane i < 18 finds both ends of the window of (row i / 2, group i % 2)
+        uint32_t sb = 0, se = 0;
+        {
+            const int slot = lane < 9 * kMxGroups ? lane : 0;
+            const int r = slot / kMxGroups, gg = slot % kMxGroups;
+            const int lo_fx = __shfl(fxl, gg * kMxGroupLanes, kWave);
+            const int hi_fx = __shfl(fxl, gg * kMxGroupLanes + kMxGroupLanes - 1, kWave);
+            const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
+            if (lane < 9 * kMxGroups && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                const uint32_t nrow = (uint32_t)(zz * g.ny + yy);
+                const uint2 rb = row_bounds[nrow];
+                const uint32_t rbk = nrow * (uint32_t)g.nx;
+                const int xa = lo_fx > g.xreach ? lo_fx - g.xreach : 0;
+                const int xb = hi_fx + g.xreach < g.nx - 1 ? hi_fx + g.xreach : g.nx - 1;
+                const uint32_t key_b = rbk + (uint32_t)xa, key_e = rbk + (uint32_t)xb + 1u;
+                uint32_t lo1 = rb.x, hi1 = rb.y, lo2 = rb.x, hi2 = rb.y;
+                while (lo1 < hi1 || lo2 < hi2) {
+                    const uint32_t m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
+                    const uint32_t k1 = skeys[m1 < n ? m1 : n - 1u], k2 = skeys[m2 < n ? m2 : n - 1u];
+                    if (lo1 < hi1) { if (k1 < key_b) lo1 = m1 + 1u; else hi1 = m1; }
+                    if (lo2 < hi2) { if (k2 < key_e) lo2 = m2 + 1u; else hi2 = m2; }
                 }
-                remaining &= ~same;
+                sb = lo1; se = lo2;
             }
         }
+        // one origin per tile for the moment features: the tile's middle query (any point near the tile will do)
+        const int mid = (int)(qn >> 1);
+        const float ox = __builtin_amdgcn_readlane(q.x, mid), oy = __builtin_amdgcn_readlane(q.y, mid),
+                    oz = __builtin_amdgcn_readlane(q.z, mid);
+        const float big = g.r2_scale;
+        const v2f neg_big = {-big, -big}, r2_big = {g.r2 * big, g.r2 * big};
+        const int ngroups = qn > (uint32_t)kMxGroupLanes ? 2 : 1;  // (a second group of repeated queries is skipped)
+        f32x16 acc[kMxGroups];
+#pragma unroll
+        for (int gi = 0; gi < kMxGroups; ++gi)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[gi][k] = 0.f;
+
+        auto row_begin = [&](int r) -> uint32_t { return __builtin_amdgcn_readlane(sb, r * kMxGroups); };
+        auto row_end = [&](int r) -> uint32_t { return __builtin_amdgcn_readlane(se, r * kMxGroups + ngroups - 1); };
+        int nr = 0;
+        uint32_t nc0 = 0, nlen = 0;
+        auto seek = [&](int r, uint32_t c) {
+            nlen = 0;
+            while (r < 9) {
+                const uint32_t e = row_end(r);
+                if (c < e) { nr = r; nc0 = c; nlen = (e - c < (uint32_t)kMxChunk) ? e - c : (uint32_t)kMxChunk; return; }
+                ++r;
+                if (r < 9) c = row_begin(r);
+            }
+        };
+        seek(0, row_begin(0));
+        while (nlen) {
+            const int r = nr;
+            const uint32_t c0 = nc0, clen = nlen;
+            wave_lds_fence();  // previous chunk fully consumed
+            // ---- stage the chunk: each lane takes candidate PAIRS (two bf16 of a feature row make one dword)
+#pragma unroll
+            for (int k = 0; k < (kMxChunk + kMxPad + 2 * kWave - 1) / (2 * kWave); ++k) {
+                const uint32_t i = 2u * (uint32_t)lane + (uint32_t)k * 2u * kWave;
+                if (i < clen + kMxPad && i < (uint32_t)(kMxChunk + kMxPad)) {
+                    const bool va = i < clen, vb = i + 1u < clen;
+                    float4 ca = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f), cb = ca;  // never within r of anything
+                    if (va) ca = spts4[c0 + i];
+                    if (vb) cb = spts4[c0 + i + 1u];
+                    *reinterpret_cast<float2 *>(wx + i) = make_float2(ca.x, cb.x);
+                    *reinterpret_cast<float2 *>(wy + i) = make_float2(ca.y, cb.y);
+                    *reinterpret_cast<float2 *>(wz + i) = make_float2(ca.z, cb.z);
+                    // features of the offsets from the tile origin (padding: all zero, never NaN/Inf in the A operand)
+                    const float uxa = va ? ca.x - ox : 0.f, uya = va ? ca.y - oy : 0.f, uza = va ? ca.z - oz : 0.f;
+                    const float uxb = vb ? cb.x - ox : 0.f, uyb = vb ? cb.y - oy : 0.f, uzb = vb ? cb.z - oz : 0.f;
+                    const uint32_t oct = i >> 3;
+                    uint32_t *fo = feat + oct * (uint32_t)kMxOctetWords + ((i & 7u) >> 1);
+                    auto st = [&](int frow, uint32_t v) { fo[frow * 4] = v; };
+                    auto split3 = [&](float a, float b, int frow) {  // exact: 8 + 8 + 8 mantissa bits
+                        const uint32_t ah = __float_as_uint(a) & 0xFFFF0000u, bh = __float_as_uint(b) & 0xFFFF0000u;
+                        st(frow, pack_hi16(bh, ah));
+                        const float ra = a - __uint_as_float(ah), rb = b - __uint_as_float(bh);
+                        const uint32_t am = __float_as_uint(ra) & 0xFFFF0000u, bm = __float_as_uint(rb) & 0xFFFF0000u;
+                        st(frow + 1, pack_hi16(bm, am));
+                        const float sa = ra - __uint_as_float(am), sb2 = rb - __uint_as_float(bm);
+                        st(frow + 2, pack_hi16(__float_as_uint(sb2), __float_as_uint(sa)));
+                    };
+                    st(0, 0x3F803F80u);  // the count row: 1.0 | 1.0
+                    split3(uxa, uxb, 1); split3(uya, uyb, 4); split3(uza, uzb, 7);
+                    split3(uxa * uxa, uxb * uxb, 10); split3(uxa * uya, uxb * uyb, 13); split3(uxa * uza, uxb * uzb, 16);
+                    split3(uya * uya, uyb * uyb, 19); split3(uya * uza, uyb * uzb, 22); split3(uza * uza, uzb * uzb, 25);
+                }
+            }
+            wave_lds_fence();
+            if (c0 + clen < row_end(r)) seek(r, c0 + clen); else seek(r + 1, r + 1 < 9 ? row_begin(r + 1) : 0u);
+#pragma unroll
+            for (int gi = 0; gi < kMxGroups; ++gi) {
+                if (gi >= ngroups) break;  // wave-uniform
+                // this group's window inside the chunk, start aligned down to an octet
+                const uint32_t mb = __builtin_amdgcn_readlane(sb, r * kMxGroups + gi),
+                               me = __builtin_amdgcn_readlane(se, r * kMxGroups + gi);
+                uint32_t ob = mb > c0 ? mb - c0 : 0u, oe = me > c0 ? me - c0 : 0u;
+                if (ob > clen) ob = clen;
+                if (oe > clen) oe = clen;
+                ob &= ~7u;
+                const int steps = oe > ob ? (int)((oe - ob + 15u) >> 4) : 0;  // wave-uniform: the MFMA needs every lane
+#ifdef GM_NORMALS_STATS
+                if (lane == 0) {
+                    atomicAdd(&ctr->pad[0], (uint32_t)(steps * 16) / 2u);  // candidates streamed per query, in 64-query tile units
+                    atomicAdd(&ctr->pad[1], (oe > ob ? oe - ob : 0u) * 2u);
+                    if (gi == 0) { atomicAdd(&ctr->pad[2], clen); atomicAdd(&ctr->pad[3], 1u); }
+                }
+#endif
+                // the query this lane stands for in this group's loop
+                const float gqa = __shfl(q.x, gi * kMxGroupLanes + qsel, kWave), gqb = __shfl(q.y, gi * kMxGroupLanes + qsel, kWave),
+                            gqc = __shfl(q.z, gi * kMxGroupLanes + qsel, kWave);
+                const v2f qx = {gqa, gqa}, qy = {gqb, gqb}, qz = {gqc, gqc};
+                // this lane's octet of the current step: candidates pw[0..7], feature rows at fa
+                const float *pw = wx + ob + 8u * (uint32_t)half;
+                const uint32_t *fa = feat + ((ob >> 3) + (uint32_t)half) * (uint32_t)kMxOctetWords + (uint32_t)qsel * 4u;
+                constexpr int W = kMxChunk + kMxPad;  // x -> y -> z stride of the SoA window
+                auto ld4 = [](const float *q4) { return *reinterpret_cast<const float4 *>(q4); };
+                float4 x0 = ld4(pw), x1 = ld4(pw + 4), y0 = ld4(pw + W), y1 = ld4(pw + W + 4), z0 = ld4(pw + 2 * W),
+                       z1 = ld4(pw + 2 * W + 4);
+                for (int it = 0; it < steps; ++it) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(fa);  // consumed by the MFMA at the end of the step
+                    // offsets from this lane's query: after these the candidate registers are dead, and the NEXT step's
+                    // reads are issued right here, a whole step of arithmetic ahead of their use (the last step reads
+                    // 16 slots past the window: inside the slack behind the padding, never used)
+                    const v2f dx0 = (v2f){x0.x, x0.y} - qx, dx1 = (v2f){x0.z, x0.w} - qx, dx2 = (v2f){x1.x, x1.y} - qx, dx3 = (v2f){x1.z, x1.w} - qx;
+                    const v2f dy0 = (v2f){y0.x, y0.y} - qy, dy1 = (v2f){y0.z, y0.w} - qy, dy2 = (v2f){y1.x, y1.y} - qy, dy3 = (v2f){y1.z, y1.w} - qy;
+                    const v2f dz0 = (v2f){z0.x, z0.y} - qz, dz1 = (v2f){z0.z, z0.w} - qz, dz2 = (v2f){z1.x, z1.y} - qz, dz3 = (v2f){z1.z, z1.w} - qz;
+                    pw += 16; fa += 2 * kMxOctetWords;
+                    x0 = ld4(pw); x1 = ld4(pw + 4); y0 = ld4(pw + W); y1 = ld4(pw + W + 4); z0 = ld4(pw + 2 * W); z1 = ld4(pw + 2 * W + 4);
+                    __builtin_amdgcn_sched_barrier(0);  // keep the re-issue here
+                    auto within2 = [&](const v2f dx, const v2f dy, const v2f dz) -> uint32_t {
+                        // FLANN L2_Simple: every product and sum rounded, in this order; RadiusResultSet: strict d2 < r2
+                        const v2f d2 = pk_add_rn(pk_add_rn(pk_mul_rn(dx, dx), pk_mul_rn(dy, dy)), pk_mul_rn(dz, dz));
+                        const v2f wgt = pk_within(d2, neg_big, r2_big);  // 1.0f / 0.0f: exact in bf16
+                        return pack_hi16(__float_as_uint(wgt.y), __float_as_uint(wgt.x));
+                    };
+                    union { bf16x8 v; uint32_t u[4]; } b;
+                    b.u[0] = within2(dx0, dy0, dz0);
+                    b.u[1] = within2(dx1, dy1, dz1);
+                    b.u[2] = within2(dx2, dy2, dz2);
+                    b.u[3] = within2(dx3, dy3, dz3);
+                    acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b.v, acc[gi], 0, 0, 0);
+                }
+            }
+        }
+        // ---- D[row][query]: lane (q, h) of group g holds rows (k & 3) + 8 (k >> 2) + 4 h in acc[g][k].  A lane's home
+        // query is query (lane & 31) of group (lane >> 5): it keeps its own half of that group's rows and swaps the
+        // other group's registers with lane ^ 32 for the missing half.
+        float own[16], got[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            own[k] = half ? acc[1][k] : acc[0][k];
+            const float snd = half ? acc[0][k] : acc[1][k];
+            got[k] = __shfl_xor(snd, 32, kWave);
+        }
+        auto frow = [&](int rr) -> double {  // feature row rr of the home query
+            const int k = 4 * (rr >> 3) + (rr & 3), hh = (rr >> 2) & 1;
+            return (double)((hh == half) ? own[k] : got[k]);
+        };
+        double mom[10];
+        mom[0] = frow(0);
+#pragma unroll
+        for (int m = 0; m < 9; ++m) mom[1 + m] = (frow(1 + 3 * m) + frow(2 + 3 * m)) + frow(3 + 3 * m);
+        const bool vox_ok = emit_normal(active, q, mom, vd, normals4, counts, qn, stat_t0);
+        if (vd.enabled) voxel_sums(vox_ok, q, vd, vox_table);
+    }
+}
+
+// ---- the neighbourhood kernel: one launch, one wave per tile, two formulations ------
+// Blocks are handed out over both tile lists: the first ceil(n_tiles_b / 4) blocks take the VALU list (its long,
+// irregular tiles start first and the regular ones fill the tail), the rest the matrix-core list.  No block is
+// long-lived: the hardware block scheduler balances the uneven candidate counts and lets the kernels of other frames
+// in flight interleave (a persistent work-queue grid measured 8 % slower alone, 4 % slower with three frames in flight).
+// XCD-aware mapping of the matrix-core list: the dispatcher deals consecutive blocks round-robin to the 8 XCDs, each
+// with its own L2; the list is in (nearly) sorted order, so neighbouring tiles share candidate rows.  Blocks are
+// re-labelled bijectively so that runs of xcd_chunk consecutive blocks land on ONE XCD (a sorted row is then fetched
+// into one L2 instead of all eight), runs are dealt round-robin; the tail that does not fill 8 runs keeps the plain order.
+constexpr int kNormalsLdsBytes = kMxLdsBytes > kValuLdsBytes ? kMxLdsBytes : kValuLdsBytes;
+__global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs A)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kNormalsLdsBytes];
+    const uint32_t w = threadIdx.x / kWave;
+    uint32_t nta = A.ctr->n_tiles, ntb = A.ctr->n_tiles_b;   // final before the launch (k_build_tiles)
+    if (nta > A.tiles_cap) nta = A.tiles_cap;
+    if (ntb > A.tiles_cap - nta) ntb = A.tiles_cap - nta;
+    const uint32_t nba = (nta + kNrWaves - 1) / kNrWaves, nbb = (ntb + kNrWaves - 1) / kNrWaves, nv = nba + nbb;
+    const bool one_to_one = gridDim.x >= nv;
+    for (uint32_t vb = blockIdx.x; vb < nv; vb += gridDim.x) {   // every wave of a block takes the same trips
+        if (vb < nbb) {
+            const uint32_t t = vb * kNrWaves + w;
+            if (t < ntb) normals_tile_valu(A, lds, A.tiles[A.tiles_cap - 1u - t]);
+        } else {
+            uint32_t va = vb - nbb;
+            const uint32_t cb = A.vd.xcd_chunk;
+            if (one_to_one && cb) {
+                const uint32_t full = nba / (8u * cb) * (8u * cb);
+                if (va < full) {
+                    const uint32_t xcd = va % 8u, slot = va / 8u;   // (va % 8 labels the XCD up to a fixed rotation)
+                    va = ((slot / cb) * 8u + xcd) * cb + slot % cb;
+                }
+            }
+            const uint32_t t = va * kNrWaves + w;
+            if (t < nta) normals_tile_mx(A, lds, A.tiles[t]);
+        }
+        if (!one_to_one) __syncthreads();   // the next trip may reinterpret the block's LDS for the other formulation
     }
 }
 
@@ -565,11 +896,16 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(256), 0, s, (const float4 *)sl.crop4, (const uint32_t *)perm,
                        (const uint32_t *)skeys, (const uint32_t *)&sl.ctr->n_cropped, (uint32_t)g.nx, sl.spts4,
                        sl.row_bounds);
+    // GM_NORMALS_IMPL: auto (default) = short tiles of dense rows on the matrix cores, long / sparse tiles on the VALU kernel;
+    // valu / mfma force one formulation for every tile (A/B measurements, cross-checks in tests)
+    static const char *impl = getenv("GM_NORMALS_IMPL");
+    const uint32_t mx_mode = !impl ? 1u : (impl[0] == 'v' ? 0u : (impl[0] == 'm' ? 2u : 1u));
     hipLaunchKernelGGL(k_build_tiles, dim3((n_cap + 1023) / 1024), dim3(1024), 0, s, (const uint32_t *)skeys, sl.ctr, (uint32_t)g.nx,
-                       (uint32_t)(kTileSpan * (g.xreach - 1)), (const uint2 *)sl.row_bounds, sl.tiles, sl.tiles_cap);
-    // one wave per tile: four tiles per block
+                       (uint32_t)(kTileSpan * (g.xreach - 1)), (uint32_t)(kMxSpan * (g.xreach - 1)), mx_mode, (const uint2 *)sl.row_bounds,
+                       sl.tiles, sl.tiles_cap);
+    // one wave per tile: four tiles per block (+ 1: each of the two lists may end in a partly filled block)
     const uint32_t mt = max_tiles(n_cap, g);
-    uint32_t nb = (mt + kNrWaves - 1) / kNrWaves;
+    uint32_t nb = (mt + kNrWaves - 1) / kNrWaves + 1;
     {
         // one wave per tile up to 65 536 blocks (262 144 tiles: a ~16 M-point frame), grid-stride beyond that.
         // GM_NORMALS_BLOCKS lowers the cap: tests use it to force the grid-stride path on a small frame.
@@ -583,10 +919,12 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     static const char *xc = getenv("GM_NORMALS_XCD");
     VoxDense vdx = vd;
     vdx.xcd_chunk = xc ? (uint32_t)atoi(xc) : 32u;
+    NormalsArgs na;
+    na.spts4 = sl.spts4; na.skeys = skeys; na.tiles = sl.tiles; na.ctr = sl.ctr; na.g = g; na.tiles_cap = sl.tiles_cap;
+    na.row_bounds = sl.row_bounds; na.normals4 = sl.normals4; na.counts = keep_counts ? sl.counts : (int32_t *)nullptr;
+    na.vd = vdx; na.vox_table = sl.vox_table;
     hipEventRecord(sl.ev_k0, s);
-    hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), 0, s, (const float4 *)sl.spts4, (const uint32_t *)skeys,
-                       (const uint2 *)sl.tiles, sl.ctr, g, sl.tiles_cap, (const uint2 *)sl.row_bounds, sl.normals4,
-                       keep_counts ? sl.counts : (int32_t *)nullptr, vdx, sl.vox_table);
+    hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), 0, s, na);
     hipEventRecord(sl.ev_k1, s);
 }
 

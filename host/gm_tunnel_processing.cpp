@@ -121,6 +121,17 @@ PointCloud Processor::voxelCentroids()
     return out;
 }
 
+NormalCloud Processor::voxelNormals()
+{
+    uint32_t n = 0;
+    gm_status s = gm_get_voxel_normals(ctx_, 0, 0, 0, &n);
+    if (s != GM_OK && s != GM_ERR_CAPACITY) check(s, "voxelNormals");
+    NormalCloud out(n ? n : 1);
+    check(gm_get_voxel_normals(ctx_, 0, &out[0].normal[0], (uint32_t)out.size(), &n), "voxelNormals");
+    out.resize(n);
+    return out;
+}
+
 // ---- marker formatting: src/tunnel_processing.cpp:161-205, 225-256, 260-300 ----
 
 Marker Processor::rvizArrow(const Vector3f &start, const Vector3f &end, const Vector3f &scale, const Vector4f &color,
@@ -171,6 +182,22 @@ MarkerArray Processor::rvizNormals(const double &leafSize, const PointCloud &clo
         const Vector3f s = {{vox[i].x, vox[i].y, vox[i].z}};
         const Normal &nn = nrm.at((size_t)idx[i]);
         const Vector3f e = {{nn.normal[0], nn.normal[1], nn.normal[2]}};   // :247-249: the arrow END is the normal itself
+        out[i] = rvizArrow(s, e, scale, color, "normals", (int)i);
+    }
+    return out;
+}
+
+MarkerArray Processor::rvizNormalsFromFrame()
+{
+    const PointCloud vox = voxelCentroids();                  // :217-220, computed inside the frame
+    const NormalCloud vn = voxelNormals();                    // :239 + :247-249, gathered on the device
+    MarkerArray out(vox.size());
+    const Vector3f scale = {{0.025f, 0.075f, 0.0625f}};       // :230
+    const Vector4f color = {{1, 0, 0, 1}};                    // :231
+    for (size_t i = 0; i < vox.size(); ++i) {
+        const Vector3f s = {{vox[i].x, vox[i].y, vox[i].z}};
+        const Normal &nn = vn.at(i);
+        const Vector3f e = {{nn.normal[0], nn.normal[1], nn.normal[2]}};
         out[i] = rvizArrow(s, e, scale, color, "normals", (int)i);
     }
     return out;

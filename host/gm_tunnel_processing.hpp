@@ -76,11 +76,16 @@ public:
     PointCloud choppedCloud();        // /choppedCloud of the last frame
     NormalCloud normals();
     PointCloud voxelCentroids();
+    NormalCloud voxelNormals();       // normals->at(kIndices[0]) per voxel centroid (needs GM_CFG_NEAREST)
 
     // ---- tunnel_processing.hpp:66-85 (pure host formatting, no device work) ----
     static Marker rvizArrow(const Vector3f &start, const Vector3f &end, const Vector3f &scale, const Vector4f &color,
                             const std::string &ns, const int &id = 0, const std::string &frame = "/velodyne");
     MarkerArray rvizNormals(const double &leafSize, const PointCloud &cloud, const NormalCloud &normals);
+    // the same markers from what the last processFrame already left on the device (context created with
+    // GM_CFG_NEAREST): voxel centroids + the normal of each centroid's nearest point -- a few KB of D2H, no second
+    // voxel grid / 1-NN pass, no upload of the cloud
+    MarkerArray rvizNormalsFromFrame();
     static MarkerArray rvizEigens(const Vector3f &eigenVals, const Matrix3f &eigenVecs);
     // The reference's unfinished cylinder output (getCylinder stub src/tunnel_processing.cpp:149-154, publisher
     // "centerAxisOutput" of type Marker src/geometric_mapping.cpp:41,119-121,163-165, param displayCylinder

@@ -161,11 +161,17 @@ gm_status gm_wait_frame(gm_ctx *ctx, uint32_t slot, gm_frame_result *res);
  *   normals     : rows nx,ny,nz,curvature (the meaningful fields of pcl::Normal)
  *   voxels      : VoxelGrid centroids in ascending voxel-key order, rows x,y,z,count
  *   nearest     : for each voxel centroid, index (into the cropped cloud) of its
- *                 nearest point (needs GM_CFG_NEAREST) */
+ *                 nearest point (needs GM_CFG_NEAREST)
+ *   voxel normals: normals->at(kIndices[0]) of rvizNormals' marker loop
+ *                 (src/tunnel_processing.cpp:237-249): the normal (nx,ny,nz,curvature) of that nearest
+ *                 point, one row per voxel centroid, gathered on the device (needs GM_CFG_NEAREST) --
+ *                 with the centroids this is everything /surfaceNormals needs, a few KB instead of
+ *                 the whole normals cloud */
 gm_status gm_get_cropped_xyz(gm_ctx *ctx, uint32_t slot, float *xyzw, uint32_t capacity, uint32_t *n_out);
 gm_status gm_get_normals(gm_ctx *ctx, uint32_t slot, float *nxyzc, uint32_t capacity, uint32_t *n_out);
 gm_status gm_get_voxel_centroids(gm_ctx *ctx, uint32_t slot, float *xyzc, uint32_t capacity, uint32_t *n_out);
 gm_status gm_get_voxel_nearest(gm_ctx *ctx, uint32_t slot, int32_t *idx, uint32_t capacity, uint32_t *n_out);
+gm_status gm_get_voxel_normals(gm_ctx *ctx, uint32_t slot, float *nxyzc, uint32_t capacity, uint32_t *n_out);
 /* per-point neighbour counts of the cropped cloud, pre-compaction order (GM_CFG_KEEP_COUNTS) */
 gm_status gm_get_neighbor_counts(gm_ctx *ctx, uint32_t slot, int32_t *counts, uint32_t capacity, uint32_t *n_out);
 /* extension: per-point segment label of the valid cloud: 0 none, 1 plane, 2 cylinder */

@@ -16,14 +16,17 @@
 // and replaces the PCL/Eigen arithmetic of cloud_cb (:48-125) with ONE call into
 // the C ABI (gm_process_frame reads the PointCloud2 rows directly: no pcl::fromROSMsg).
 //
-// NOT COMPILED in this repository's CI: ROS is absent from the build image
-// (SURVEY.md Appendix B).  Build it in a catkin workspace with ros/CMakeLists.txt.
+// ROS is absent from the build image: here the node is only TYPE-CHECKED against minimal
+// stand-in headers (tests/stubs/, tests/test_ros_node_compiles.py).  Build it for real in a catkin workspace with
+// ros/CMakeLists.txt.
 // Deliberate differences from the reference, all on non-default paths:
 //   * usePCLViz is accepted and ignored with a warning (the reference stores the
 //     address of a block-local PCLVisualizer: dangling, src/geometric_mapping.cpp:140-143);
 //   * nothing is heap-allocated per frame (the reference leaks 5 objects per callback);
 //   * 1-NN for /surfaceNormals searches the compacted cloud (the reference's kd-tree
-//     still indexes the pre-compaction cloud, src/tunnel_processing.cpp:65,85,239).
+//     still indexes the pre-compaction cloud, src/tunnel_processing.cpp:65,85,239);
+//   * with displayNormals the context is created with GM_CFG_NEAREST: the voxel grid, the 1-NN and the gather of
+//     the nearest points' normals all happen inside the one frame pass, the node fetches V centroids + V normals.
 #include <ros/ros.h>
 #include <sensor_msgs/PointCloud2.h>
 #include <sensor_msgs/PointField.h>
@@ -31,6 +34,7 @@
 
 #include <cstring>
 #include <memory>
+#include <vector>
 
 #include "../host/gm_tunnel_processing.hpp"
 
@@ -112,7 +116,18 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input)
     gm_frame_result r;
     try {
         // fromROSMsg + chopCloud + getNormals + VoxelGrid + getLocalFrame: one device pass (:55-92)
-        r = proc->processFrame(n ? &input->data[0] : nullptr, n, input->point_step, ox, oy, oz, input->is_bigendian);
+        const unsigned char *rows = n ? &input->data[0] : nullptr;
+        std::vector<unsigned char> packed;
+        if (n && input->height > 1 && input->row_step != input->width * input->point_step) {
+            // organised cloud with padded rows: pcl::fromROSMsg honours row_step, the C ABI takes point_step-strided
+            // rows -- drop the padding once on the host
+            packed.resize((size_t)n * input->point_step);
+            for (uint32_t y = 0; y < input->height; ++y)
+                std::memcpy(&packed[(size_t)y * input->width * input->point_step], &input->data[(size_t)y * input->row_step],
+                            (size_t)input->width * input->point_step);
+            rows = &packed[0];
+        }
+        r = proc->processFrame(rows, n, input->point_step, ox, oy, oz, input->is_bigendian);
     } catch (const gm_host::Error &e) {
         ROS_ERROR("libgm_hip: %s", e.what());
         return;
@@ -141,11 +156,8 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input)
         if (!cloud.empty()) std::memcpy(&out.data[0], &cloud[0], out.data.size());
         cloudPub.publish(out);
     }
-    if (params->rvizNormals) {  // :109-112
-        gm_host::PointCloud cloud = proc->choppedCloud();
-        const gm_host::NormalCloud nrm = proc->normals();
-        normalsPub.publish(to_ros(proc->rvizNormals(params->leafSize, cloud, nrm)));
-    }
+    if (params->rvizNormals)  // :109-112: centroids + nearest normals were produced inside the frame (GM_CFG_NEAREST)
+        normalsPub.publish(to_ros(proc->rvizNormalsFromFrame()));
     if (params->rvizCenterAxis)  // :114-117
         centerAxisPub.publish(to_ros(gm_host::Processor::rvizEigens(vals, vecs)));
     if (params->rvizCylinder) {  // the reference's commented-out block :119-121
@@ -167,7 +179,8 @@ int main(int argc, char **argv)
     try {
         proc.reset(new gm_host::Processor(params->boxFilterBound, params->leafSize, params->neighborRadius,
                                           params->weightingFactor, 0,
-                                          GM_CFG_DEFAULT | (params->rvizCylinder ? GM_CFG_RANSAC_CYLINDER : 0u)));
+                                          GM_CFG_DEFAULT | (params->rvizCylinder ? GM_CFG_RANSAC_CYLINDER : 0u) |
+                                              (params->rvizNormals ? GM_CFG_NEAREST : 0u)));
     } catch (const gm_host::Error &e) {
         ROS_FATAL("libgm_hip: %s", e.what());
         return 1;

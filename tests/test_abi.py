@@ -103,3 +103,17 @@ def test_solve_local_frame_host_entry(oc):
     w, W = oc.eig3(M)
     assert np.allclose(ev, w, rtol=1e-6) and np.all(np.diff(ev) >= 0)
     assert np.allclose(np.abs((V * W).sum(axis=0)), 1.0, atol=1e-5)
+
+
+def test_solve_local_frame_has_the_eigenvector_signs_of_the_f32_faithful_solve():
+    """Eigenvector signs are arbitrary mathematically but visible on /eigenBasisOutput (arrow directions).  The library
+    returns fp64-Jacobi eigenpairs whose column signs are those of Eigen's float tridiagonal-QR sequence
+    (SelfAdjointEigenSolver<MatrixXf>, /root/reference src/tunnel_processing.cpp:129) as the oracle restates it."""
+    import glob
+    import geometric_mapping_amd as g
+    for p in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz"))):
+        d = np.load(p)
+        M = d["M_f32"]
+        ev, V = g.solve_local_frame(np.array([M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2]]))
+        dots = (V.astype(np.float64) * d["evecs_f32"].astype(np.float64)).sum(axis=0)
+        assert np.all(dots > 0.9999), (p, dots)

