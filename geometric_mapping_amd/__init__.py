@@ -16,7 +16,7 @@ def load_library():
 
 
 def __getattr__(name):
-    if name in ("GeometricMapping", "GmError", "solve_local_frame", "decode_compressed_map"):
+    if name in ("GeometricMapping", "GeometricMappingGroup", "GmError", "solve_local_frame", "decode_compressed_map"):
         from . import api
         return getattr(api, name)
     raise AttributeError(name)

@@ -23,6 +23,8 @@ GM_ERR_OOM = 4
 GM_ERR_CAPACITY = 5
 GM_ERR_NOT_READY = 6
 GM_ERR_UNSUPPORTED = 7
+GM_ERR_COMM = 8
+GM_GROUP_LOOPBACK = 1
 
 GM_CFG_VOXEL_GRID = 1 << 0
 GM_CFG_NEAREST = 1 << 1
@@ -151,6 +153,13 @@ def load():
         "gm_cylinder_hypotheses": (C.c_int, [vp, fp, fp, u32, u8p, u32, C.c_uint64, u32, fp]),
         "gm_segment_moments": (C.c_int, [vp, fp, fp, u8p, u32, u32, dp]),
         "gm_get_compressed_map": (C.c_int, [vp, u32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+        "gm_group_create": (C.c_int, [cfgp, i32p, u32, u32, C.POINTER(vp)]),
+        "gm_group_destroy": (None, [vp]),
+        "gm_group_size": (u32, [vp]),
+        "gm_group_ctx": (vp, [vp, u32]),
+        "gm_group_last_error": (C.c_char_p, [vp]),
+        "gm_group_process_frame": (C.c_int, [vp, cloudp, resp]),
+        "gm_group_get_cropped_xyz": (C.c_int, [vp, fp, u32, u32p]),
     }
     for name, (res, args) in proto.items():
         fn = getattr(L, name)  # AttributeError if the .so does not export it

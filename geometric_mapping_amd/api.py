@@ -19,7 +19,7 @@ from . import _lib
 from ._lib import (GM_CFG_DEFAULT, GM_CFG_KEEP_COUNTS, GM_CFG_STAGE_TIMING, GM_CFG_VOXEL_GRID, GM_CLOUD_BIGENDIAN,
                    GM_CLOUD_DEVICE, GM_CLOUD_PINNED, GM_ERR_CAPACITY, GM_OK, Cloud, Config, FrameResult, GmError, STAGE_NAMES)
 
-__all__ = ["GeometricMapping", "GmError", "solve_local_frame", "decode_compressed_map"]
+__all__ = ["GeometricMapping", "GeometricMappingGroup", "GmError", "solve_local_frame", "decode_compressed_map"]
 
 
 def _f32(a):
@@ -354,6 +354,66 @@ def decode_compressed_map(buf):
     vox = np.frombuffer(buf, np.float32, 4 * int(nvox), off).reshape(-1, 4).copy()
     return dict(version=int(version), leaf=float(leaf), bound=float(bound), n_points=n_points, eigenvalues=ev,
                 center_axis=axis, primitives=prims, voxels=vox)
+
+
+class GeometricMappingGroup:
+    """gm_group: one host thread driving every listed GPU; ONE frame sharded spatially across them with an in-library
+    RCCL all-gather of the per-rank records (include/gm_hip.h, "multi-device group").  devices=[0, 0, ...] with
+    loopback=True runs several ranks on one GPU (tests on a 1-GPU box): same code, records travel by device copies."""
+
+    def __init__(self, devices, loopback=False, **cfg_kw):
+        self._L = _lib.load()
+        cfg = Config()
+        self._L.gm_default_config(C.byref(cfg))
+        for k, v in cfg_kw.items():
+            setattr(cfg, k, v)
+        dev = (C.c_int32 * len(devices))(*devices)
+        self._grp = C.c_void_p()
+        st = self._L.gm_group_create(C.byref(cfg), dev, len(devices), _lib.GM_GROUP_LOOPBACK if loopback else 0, C.byref(self._grp))
+        if st != GM_OK:
+            msg = self._L.gm_group_last_error(None).decode()
+            self._grp = None
+            raise GmError(st, msg)
+
+    def close(self):
+        if getattr(self, "_grp", None):
+            self._L.gm_group_destroy(self._grp)
+            self._grp = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self._L.gm_group_size(self._grp))
+
+    def _check(self, st):
+        if st != GM_OK:
+            raise GmError(st, self._L.gm_group_last_error(self._grp).decode())
+
+    def process_frame(self, cloud):
+        c, keep = cloud if (isinstance(cloud, tuple) and isinstance(cloud[0], Cloud)) else GeometricMapping._cloud_from_xyz(cloud)
+        res = FrameResult()
+        self._check(self._L.gm_group_process_frame(self._grp, C.byref(c), C.byref(res)))
+        return GeometricMapping._result(res)
+
+    def cropped_cloud(self):
+        n = C.c_uint32(0)
+        st = self._L.gm_group_get_cropped_xyz(self._grp, None, 0, C.byref(n))
+        if st not in (GM_OK, GM_ERR_CAPACITY):
+            self._check(st)
+        out = np.empty((n.value, 4), dtype=np.float32)
+        if n.value:
+            self._check(self._L.gm_group_get_cropped_xyz(self._grp, _f32(out), n.value, C.byref(n)))
+        return out[:, :3].copy(), out[:, 3].copy().view(np.int32)
 
 
 def solve_local_frame(scatter6):

@@ -529,6 +529,7 @@ const char *gm_status_string(gm_status s)
     case GM_ERR_CAPACITY: return "output capacity too small";
     case GM_ERR_NOT_READY: return "not ready";
     case GM_ERR_UNSUPPORTED: return "unsupported";
+    case GM_ERR_COMM: return "communication (RCCL) error";
     }
     return "unknown";
 }

@@ -15,8 +15,8 @@ constexpr int kWave = 64;
 struct DevCounters {
     uint32_t n_cropped;   // points surviving the crop box
     uint32_t n_valid;     // points with a finite normal (and owned, when sharded)
-    uint32_t n_tiles;     // query tiles for the matrix-core kernel (stored from the front of the tile list)
-    uint32_t n_tiles_b;   // query tiles for the all-VALU kernel (sparse / long tiles; stored from the back)
+    uint32_t n_tiles;     // query tiles built from the sorted cell keys
+    uint32_t reserved0;
     uint32_t n_voxels;    // occupied voxels
     uint32_t vox_n;       // points entering the voxel grid (= n_valid)
     uint32_t mm[6];       // ordered-uint encodings: min x,y,z then max x,y,z of the valid cloud

@@ -107,18 +107,13 @@ __global__ __launch_bounds__(256) void k_gather_sorted(const float4 *__restrict_
 // full tiles: ~90 % lane fill) and a 64-chunk that spans more than `span` cell steps (sparse
 // rows) is cut again at aligned (span+1)-cell groups, which bounds the candidate count of a
 // tile: without the bound a sparse row yields tiles 20x the mean that the whole grid waits for.
-// Two lists come out: tiles whose 64-chunk is short (<= mx_span fine cells: dense rows) go to the matrix-core kernel
-// (front of `tiles`, count n_tiles); long / span-cut tiles of sparse rows go to the all-VALU kernel (back of `tiles`,
-// count n_tiles_b), whose offsets-from-the-own-query accumulation keeps its precision however far a tile stretches
-// and which has no per-tile feature staging to amortise over a handful of candidates.
 __global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict__ skeys,
                                                       DevCounters *__restrict__ ctr, uint32_t nx, uint32_t span,
-                                                      uint32_t mx_span, uint32_t mx_mode /* 0 none, 1 by span, 2 all */,
                                                       const uint2 *__restrict__ row_bounds,
                                                       uint2 *__restrict__ tiles, uint32_t tiles_cap)
 {
-    __shared__ uint32_t wtot[2][1024 / kWave];
-    __shared__ uint32_t block_base[2];
+    __shared__ uint32_t wtot[1024 / kWave];
+    __shared__ uint32_t block_base;
     const uint32_t n = ctr->n_cropped;
     const uint32_t s = blockIdx.x * 1024u + threadIdx.x;
     if (blockIdx.x * 1024u >= n) return;  // uniform per block
@@ -126,16 +121,13 @@ __global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict
     // a point starts a tile iff it starts a 64-chunk of its x-row, or its chunk is "sparse"
     // (spans more than `span` cell steps) and it is the first point of an aligned cell group
     uint32_t cnt = 0, tend = 0;
-    bool to_mx = false;
     if (s < n) {
         const uint32_t key = skeys[s];
         const uint32_t row = key / nx;
         const uint2 rb = row_bounds[row];  // written by k_gather_sorted
         const uint32_t cstart = rb.x + ((s - rb.x) / (uint32_t)kTileQ) * (uint32_t)kTileQ;
         const uint32_t cend = (cstart + kTileQ < rb.y) ? cstart + kTileQ : rb.y;
-        const uint32_t extent = skeys[cend - 1] - skeys[cstart];     // same row: key difference = cell steps
-        const bool sparse = extent > span;
-        to_mx = mx_mode == 2u || (mx_mode == 1u && extent <= mx_span);
+        const bool sparse = skeys[cend - 1] - skeys[cstart] > span;  // same row: key difference = cell steps
         const uint32_t group = span + 1u;
         const uint32_t my_group = (key - row * nx) / group;
         if (s == cstart) cnt = 1;
@@ -154,26 +146,21 @@ __global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict
             }
         }
     }
-    // block-wide exclusive prefix of the flags of each list, ONE atomic per block and list for the base
-    const uint32_t ca = (cnt && to_mx) ? 1u : 0u, cb = (cnt && !to_mx) ? 1u : 0u;
-    const uint32_t inca = wave_inclusive_scan(ca), incb = wave_inclusive_scan(cb);
-    if (lane_id() == kWave - 1) { wtot[0][w] = inca; wtot[1][w] = incb; }
+    // block-wide exclusive prefix of the flags, ONE atomic per block for the base
+    const uint32_t inc = wave_inclusive_scan(cnt);
+    if (lane_id() == kWave - 1) wtot[w] = inc;
     __syncthreads();
-    uint32_t woffa = 0, tota = 0, woffb = 0, totb = 0;
+    uint32_t woff = 0, total = 0;
 #pragma unroll
     for (int k = 0; k < 1024 / kWave; ++k) {
-        const uint32_t c0 = wtot[0][k], c1 = wtot[1][k];
-        if (k < w) { woffa += c0; woffb += c1; }
-        tota += c0; totb += c1;
+        const uint32_t c = wtot[k];
+        if (k < w) woff += c;
+        total += c;
     }
-    if (threadIdx.x == 0) {
-        block_base[0] = tota ? atomicAdd(&ctr->n_tiles, tota) : 0u;
-        block_base[1] = totb ? atomicAdd(&ctr->n_tiles_b, totb) : 0u;
-    }
+    if (threadIdx.x == 0) block_base = total ? atomicAdd(&ctr->n_tiles, total) : 0u;
     __syncthreads();
-    // (the two lists grow towards each other and together never hold more than tiles_cap entries: max_tiles())
-    if (ca) { const uint32_t t_out = block_base[0] + woffa + inca - 1u; if (t_out < tiles_cap) tiles[t_out] = make_uint2(s, tend - s); }
-    if (cb) { const uint32_t t_out = block_base[1] + woffb + incb - 1u; if (t_out < tiles_cap) tiles[tiles_cap - 1u - t_out] = make_uint2(s, tend - s); }
+    const uint32_t t_out = block_base + woff + inc - cnt;
+    if (cnt && t_out < tiles_cap) tiles[t_out] = make_uint2(s, tend - s);  // first query, number of queries
 }
 
 // ---- smallest eigenpair of a symmetric PSD 3x3, fp64 ----------------------------
@@ -330,8 +317,9 @@ struct NormalsArgs {
 };
 
 // ---- one tile, all-VALU formulation ------------------------------------------------
-// (long / sparse tiles: the list k_build_tiles stores from the back of `tiles`)
-constexpr int kValuLdsBytes = kNrWaves * 3 * (kWinCap + kWinPad) * 4 + kNrWaves * 10 * kWave * 8;
+// `lds` is THIS WAVE's slice of the block's LDS (the two formulations never share a slice across waves, so the waves of
+// a block choose their formulation independently and no block barrier exists anywhere).
+constexpr int kValuWaveLdsBytes = 3 * (kWinCap + kWinPad) * 4 + 10 * kWave * 8;
 __device__ __forceinline__ void normals_tile_valu(const NormalsArgs &A, unsigned char *lds, const uint2 tile)
 {
     const float4 *__restrict__ spts4 = A.spts4;
@@ -348,10 +336,10 @@ __device__ __forceinline__ void normals_tile_valu(const NormalsArgs &A, unsigned
     // the x (or y, z) of FOUR candidates to every lane; then the per-lane fp64 moment totals of the tile
     typedef float WinT[3][kWinCap + kWinPad];
     typedef double TotT[10][kWave];
-    WinT *win = reinterpret_cast<WinT *>(lds);
-    TotT *tot = reinterpret_cast<TotT *>(lds + sizeof(WinT) * kNrWaves);
+    WinT *win = reinterpret_cast<WinT *>(lds);            // indexed [0] below: the slice is already this wave's
+    TotT *tot = reinterpret_cast<TotT *>(lds + sizeof(WinT));
     const int lane = lane_id();
-    const int w = threadIdx.x / kWave;
+    const int w = 0;
     const uint32_t n = ctr->n_cropped;
     {
         const uint32_t qs = tile.x, qn = tile.y;  // first query (sorted position), number of queries (1..64)
@@ -590,14 +578,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 constexpr int kMxChunk = GM_MXCHUNK;      // candidates staged per chunk of a row range (multiple of 16)
 constexpr int kMxPad = 16;                // far-away padding behind a chunk (the last 16-candidate block of a group)
-#ifndef GM_MXSPAN
-#define GM_MXSPAN 2
+#ifndef GM_MXMINCAND
+#define GM_MXMINCAND 64
 #endif
-constexpr int kMxSpan = GM_MXSPAN;        // longest tile (in coarse cells) the matrix-core kernel takes; longer ones go to the VALU kernel
+constexpr int kMxMinCandidates = GM_MXMINCAND;  // tiles whose first group sees fewer candidates than this take the direct path
 constexpr int kMxGroups = 2;              // query groups of a tile: 32 queries each (the N of the 32x32x16 MFMA)
 constexpr int kMxGroupLanes = kWave / kMxGroups;
 constexpr int kMxOctets = (kMxChunk + kMxPad) / 8;
-constexpr int kMxRows = 28;               // feature rows per octet: 1 + 9 x 3.  The A operand's rows 28..31 read the pad row and the
+[[maybe_unused]] constexpr int kMxRows = 28;  // feature rows per octet: 1 + 9 x 3.  The A operand's rows 28..31 read the pad row and the
                                           // next octet's first rows: whatever is there only reaches result rows nobody reads
 constexpr int kMxOctetWords = 29 * 4;     // 464 B per octet: 116 dwords = 20 mod 32 banks, so the staging stores of the 16
                                           // octets a wave writes at once spread over all banks (448 B would be 8-way conflicts)
@@ -615,9 +603,9 @@ struct MxWaveLds {
     float w[3][kMxChunk + kMxPad];
     uint32_t f[kMxOctets * kMxOctetWords + 16];
 };
-constexpr int kMxLdsBytes = (int)sizeof(MxWaveLds) * kNrWaves;
+constexpr int kMxWaveLdsBytes = (int)sizeof(MxWaveLds);
 
-__device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned char *lds, const uint2 tile)
+__device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned char *lds, const uint2 tile, uint32_t min_candidates)
 {
     const float4 *__restrict__ spts4 = A.spts4;
     const uint32_t *__restrict__ skeys = A.skeys;
@@ -629,9 +617,9 @@ __device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned c
     const VoxDense &vd = A.vd;
     VoxCell *__restrict__ vox_table = A.vox_table;
     (void)ctr;
-    MxWaveLds *mxl = reinterpret_cast<MxWaveLds *>(lds);
+    MxWaveLds *mxl = reinterpret_cast<MxWaveLds *>(lds);   // this wave's slice
     const int lane = lane_id();
-    const int w = threadIdx.x / kWave;
+    const int w = 0;
     const uint32_t n = ctr->n_cropped;
     float *wx = &mxl[w].w[0][0], *wy = &mxl[w].w[1][0], *wz = &mxl[w].w[2][0];
     uint32_t *feat = &mxl[w].f[0];
@@ -684,6 +672,16 @@ __device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned c
                 sb = lo1; se = lo2;
             }
         }
+        // Thin neighbourhoods (fewer than min_candidates candidates in the first group's windows) take the direct path
+        // below: nothing to amortise the feature staging over, and the few-point covariances of a sparse cloud are
+        // near-degenerate, where offsets from the query itself (|offset| < r) in fp64 keep more than offsets from a
+        // tile origin through bf16 features do.
+        bool thin;
+        {
+            uint32_t wl = (lane < 9 * kMxGroups && (lane % kMxGroups) == 0) ? se - sb : 0u;
+            wl = (uint32_t)wave_sum((unsigned long long)wl);
+            thin = wl < min_candidates;
+        }
         // one origin per tile for the moment features: the tile's middle query (any point near the tile will do)
         const int mid = (int)(qn >> 1);
         const float ox = __builtin_amdgcn_readlane(q.x, mid), oy = __builtin_amdgcn_readlane(q.y, mid),
@@ -692,6 +690,7 @@ __device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned c
         const v2f neg_big = {-big, -big}, r2_big = {g.r2 * big, g.r2 * big};
         const int ngroups = qn > (uint32_t)kMxGroupLanes ? 2 : 1;  // (a second group of repeated queries is skipped)
         f32x16 acc[kMxGroups];
+
 #pragma unroll
         for (int gi = 0; gi < kMxGroups; ++gi)
 #pragma unroll
@@ -710,6 +709,28 @@ __device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned c
                 if (r < 9) c = row_begin(r);
             }
         };
+        if (thin) {
+            // direct path, self-contained: every lane tests its own query against every candidate of the tile's row
+            // ranges (wave-uniform loads straight from the sorted cloud) and sums the offsets from the query in fp64
+            double tm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = 0; r < 9; ++r) {
+                const uint32_t e = row_end(r);
+                for (uint32_t i = row_begin(r); i < e; ++i) {
+                    const float4 c = spts4[i];
+                    const float dx = c.x - q.x, dy = c.y - q.y, dz = c.z - q.z;
+                    // FLANN L2_Simple: every product and sum rounded, in this order; RadiusResultSet: strict d2 < r2
+                    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                    if (d2 < g.r2) {
+                        const double ex = dx, ey = dy, ez = dz;
+                        tm[0] += 1.0; tm[1] += ex; tm[2] += ey; tm[3] += ez;
+                        tm[4] += ex * ex; tm[5] += ex * ey; tm[6] += ex * ez; tm[7] += ey * ey; tm[8] += ey * ez; tm[9] += ez * ez;
+                    }
+                }
+            }
+            const bool vox_ok = emit_normal(active, q, tm, vd, normals4, counts, qn, stat_t0);
+            if (vd.enabled) voxel_sums(vox_ok, q, vd, vox_table);
+            return;
+        }
         seek(0, row_begin(0));
         while (nlen) {
             const int r = nr;
@@ -823,49 +844,55 @@ __device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned c
         mom[0] = frow(0);
 #pragma unroll
         for (int m = 0; m < 9; ++m) mom[1 + m] = (frow(1 + 3 * m) + frow(2 + 3 * m)) + frow(3 + 3 * m);
+
         const bool vox_ok = emit_normal(active, q, mom, vd, normals4, counts, qn, stat_t0);
         if (vd.enabled) voxel_sums(vox_ok, q, vd, vox_table);
     }
 }
 
 // ---- the neighbourhood kernel: one launch, one wave per tile, two formulations ------
-// Blocks are handed out over both tile lists: the first ceil(n_tiles_b / 4) blocks take the VALU list (its long,
-// irregular tiles start first and the regular ones fill the tail), the rest the matrix-core list.  No block is
-// long-lived: the hardware block scheduler balances the uneven candidate counts and lets the kernels of other frames
-// in flight interleave (a persistent work-queue grid measured 8 % slower alone, 4 % slower with three frames in flight).
-// XCD-aware mapping of the matrix-core list: the dispatcher deals consecutive blocks round-robin to the 8 XCDs, each
-// with its own L2; the list is in (nearly) sorted order, so neighbouring tiles share candidate rows.  Blocks are
-// re-labelled bijectively so that runs of xcd_chunk consecutive blocks land on ONE XCD (a sorted row is then fetched
-// into one L2 instead of all eight), runs are dealt round-robin; the tail that does not fill 8 runs keeps the plain order.
-constexpr int kNormalsLdsBytes = kMxLdsBytes > kValuLdsBytes ? kMxLdsBytes : kValuLdsBytes;
-__global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs A)
+// Tiles are assigned by wave id (grid-stride; with the default grid every wave gets at most one tile and its block
+// retires right after).  No block is long-lived: the hardware block scheduler balances the uneven candidate counts and
+// lets the kernels of other frames in flight interleave (a persistent work-queue grid measured 8 % slower alone, 4 %
+// slower with three frames in flight).
+// XCD-aware tile mapping: the dispatcher deals consecutive blocks round-robin to the 8 XCDs, each with its own L2; the
+// tile list is in (nearly) sorted order, so neighbouring tiles share candidate rows.  Blocks are re-labelled bijectively
+// so that runs of xcd_chunk consecutive blocks land on ONE XCD (a sorted row is then fetched into one L2 instead of
+// all eight), runs are dealt round-robin; the tail that does not fill 8 runs keeps the plain order.
+constexpr int kWaveLdsBytes = (kMxWaveLdsBytes + 15) / 16 * 16;
+__device__ __forceinline__ uint32_t normals_wave_id(const NormalsArgs &A, uint32_t ntiles)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kNormalsLdsBytes];
-    const uint32_t w = threadIdx.x / kWave;
-    uint32_t nta = A.ctr->n_tiles, ntb = A.ctr->n_tiles_b;   // final before the launch (k_build_tiles)
-    if (nta > A.tiles_cap) nta = A.tiles_cap;
-    if (ntb > A.tiles_cap - nta) ntb = A.tiles_cap - nta;
-    const uint32_t nba = (nta + kNrWaves - 1) / kNrWaves, nbb = (ntb + kNrWaves - 1) / kNrWaves, nv = nba + nbb;
-    const bool one_to_one = gridDim.x >= nv;
-    for (uint32_t vb = blockIdx.x; vb < nv; vb += gridDim.x) {   // every wave of a block takes the same trips
-        if (vb < nbb) {
-            const uint32_t t = vb * kNrWaves + w;
-            if (t < ntb) normals_tile_valu(A, lds, A.tiles[A.tiles_cap - 1u - t]);
-        } else {
-            uint32_t va = vb - nbb;
-            const uint32_t cb = A.vd.xcd_chunk;
-            if (one_to_one && cb) {
-                const uint32_t full = nba / (8u * cb) * (8u * cb);
-                if (va < full) {
-                    const uint32_t xcd = va % 8u, slot = va / 8u;   // (va % 8 labels the XCD up to a fixed rotation)
-                    va = ((slot / cb) * 8u + xcd) * cb + slot % cb;
-                }
-            }
-            const uint32_t t = va * kNrWaves + w;
-            if (t < nta) normals_tile_mx(A, lds, A.tiles[t]);
+    uint32_t vblock = blockIdx.x;
+    const uint32_t nblk = (ntiles + kNrWaves - 1) / kNrWaves;
+    if (gridDim.x >= nblk && A.vd.xcd_chunk) {
+        if (blockIdx.x >= nblk) return 0xFFFFFFFFu;  // uniform per block: no tile for this block
+        const uint32_t cb = A.vd.xcd_chunk, full = nblk / (8u * cb) * (8u * cb);
+        if (blockIdx.x < full) {
+            const uint32_t xcd = blockIdx.x % 8u, slot = blockIdx.x / 8u;
+            vblock = ((slot / cb) * 8u + xcd) * cb + slot % cb;
         }
-        if (!one_to_one) __syncthreads();   // the next trip may reinterpret the block's LDS for the other formulation
     }
+    return vblock * kNrWaves + threadIdx.x / kWave;
+}
+
+__global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs A, uint32_t mx_min_candidates)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][kWaveLdsBytes];
+    uint32_t ntiles = A.ctr->n_tiles;   // final before the launch (k_build_tiles)
+    if (ntiles > A.tiles_cap) ntiles = A.tiles_cap;
+    const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
+    for (uint32_t t = wave_id; t < ntiles; t += n_waves)   // every wave reaches the end: the list is final
+        normals_tile_mx(A, lds[threadIdx.x / kWave], A.tiles[t], mx_min_candidates);
+}
+
+// the all-VALU formulation of every tile (GM_NORMALS_IMPL=valu: A/B measurements and the cross-check in tests)
+__global__ __launch_bounds__(kNrThreads) void k_normals_valu(NormalsArgs A)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][(kValuWaveLdsBytes + 15) / 16 * 16];
+    uint32_t ntiles = A.ctr->n_tiles;
+    if (ntiles > A.tiles_cap) ntiles = A.tiles_cap;
+    const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
+    for (uint32_t t = wave_id; t < ntiles; t += n_waves) normals_tile_valu(A, lds[threadIdx.x / kWave], A.tiles[t]);
 }
 
 uint32_t max_tiles(uint32_t n_cap, const GridParams &g)
@@ -896,16 +923,11 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(256), 0, s, (const float4 *)sl.crop4, (const uint32_t *)perm,
                        (const uint32_t *)skeys, (const uint32_t *)&sl.ctr->n_cropped, (uint32_t)g.nx, sl.spts4,
                        sl.row_bounds);
-    // GM_NORMALS_IMPL: auto (default) = short tiles of dense rows on the matrix cores, long / sparse tiles on the VALU kernel;
-    // valu / mfma force one formulation for every tile (A/B measurements, cross-checks in tests)
-    static const char *impl = getenv("GM_NORMALS_IMPL");
-    const uint32_t mx_mode = !impl ? 1u : (impl[0] == 'v' ? 0u : (impl[0] == 'm' ? 2u : 1u));
     hipLaunchKernelGGL(k_build_tiles, dim3((n_cap + 1023) / 1024), dim3(1024), 0, s, (const uint32_t *)skeys, sl.ctr, (uint32_t)g.nx,
-                       (uint32_t)(kTileSpan * (g.xreach - 1)), (uint32_t)(kMxSpan * (g.xreach - 1)), mx_mode, (const uint2 *)sl.row_bounds,
-                       sl.tiles, sl.tiles_cap);
-    // one wave per tile: four tiles per block (+ 1: each of the two lists may end in a partly filled block)
+                       (uint32_t)(kTileSpan * (g.xreach - 1)), (const uint2 *)sl.row_bounds, sl.tiles, sl.tiles_cap);
+    // one wave per tile: four tiles per block
     const uint32_t mt = max_tiles(n_cap, g);
-    uint32_t nb = (mt + kNrWaves - 1) / kNrWaves + 1;
+    uint32_t nb = (mt + kNrWaves - 1) / kNrWaves;
     {
         // one wave per tile up to 65 536 blocks (262 144 tiles: a ~16 M-point frame), grid-stride beyond that.
         // GM_NORMALS_BLOCKS lowers the cap: tests use it to force the grid-stride path on a small frame.
@@ -923,8 +945,14 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     na.spts4 = sl.spts4; na.skeys = skeys; na.tiles = sl.tiles; na.ctr = sl.ctr; na.g = g; na.tiles_cap = sl.tiles_cap;
     na.row_bounds = sl.row_bounds; na.normals4 = sl.normals4; na.counts = keep_counts ? sl.counts : (int32_t *)nullptr;
     na.vd = vdx; na.vox_table = sl.vox_table;
+    // GM_NORMALS_IMPL: auto (default) = moments on the matrix cores except for thin neighbourhoods (fewer than
+    // kMxMinCandidates candidates in a tile's windows), which take the kernel's direct fp64 path; mfma = matrix cores for
+    // every tile; valu = the all-VALU kernel (A/B measurements, cross-checks in tests)
+    static const char *impl = getenv("GM_NORMALS_IMPL");
+    const uint32_t mx_min = !impl ? (uint32_t)kMxMinCandidates : (impl[0] == 'v' ? 0xFFFFFFFFu : (impl[0] == 'm' ? 0u : (uint32_t)kMxMinCandidates));
     hipEventRecord(sl.ev_k0, s);
-    hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), 0, s, na);
+    if (mx_min == 0xFFFFFFFFu) hipLaunchKernelGGL(k_normals_valu, dim3(nb), dim3(kNrThreads), 0, s, na);
+    else hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
     hipEventRecord(sl.ev_k1, s);
 }
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GM_ABI_VERSION 1u
+#define GM_ABI_VERSION 2u
 
 typedef struct gm_ctx gm_ctx; /* opaque */
 
@@ -40,7 +40,8 @@ typedef enum gm_status {
     GM_ERR_OOM = 4,
     GM_ERR_CAPACITY = 5,       /* caller buffer too small; *n_out holds the needed count */
     GM_ERR_NOT_READY = 6,      /* slot has no submitted / completed frame */
-    GM_ERR_UNSUPPORTED = 7
+    GM_ERR_UNSUPPORTED = 7,
+    GM_ERR_COMM = 8            /* RCCL could not be loaded or a collective failed (gm_group_*) */
 } gm_status;
 
 /* gm_config.flags */
@@ -280,6 +281,35 @@ typedef struct gm_map_primitive {
     float    pad;
 } gm_map_primitive;
 gm_status gm_get_compressed_map(gm_ctx *ctx, uint32_t slot, void *buf, size_t capacity, size_t *n_bytes);
+
+/* ---- multi-device group: one host thread, every local GPU ---------------------
+ * The reference is one single-threaded process (ros::spin(), src/geometric_mapping.cpp:169) on one CPU core; it has
+ * no counterpart for this section.  north_star: "Frames shard spatially across the 8 GPUs of one node with an RCCL
+ * all-gather of fitted primitives over xGMI only when a scan exceeds single-GPU capacity".
+ *
+ * A group owns one gm_ctx per rank (one rank per device) and, across distinct devices, one RCCL communicator per rank
+ * (ncclCommInitAll, single process; librccl is loaded at run time).  gm_group_process_frame cuts ONE frame into
+ * x-slabs balanced by the count of in-box points, adds a 1.01 * neighborRadius halo (neighbours only, never outputs:
+ * gm_set_owned_range) ON THE HOST before H2D, runs the unchanged single-GPU pipeline on every rank asynchronously, and
+ * exchanges the results with ONE ncclAllGather of a 24-double record per rank (scatter partials, counts, the rank's
+ * fitted plane / cylinder).  The merged frame: scatter = sum of the partials (rank order), 3x3 solve, counts summed,
+ * voxels re-joined across slab edges; fitted primitives by vote -- every rank's fit is a candidate, every rank counts
+ * every candidate's inliers on its own resident owned points (gm_score_frame), the largest total wins.
+ * Frames that fit one GPU need no group: stream them round-robin over per-device contexts (gm_submit_frame). */
+typedef struct gm_group gm_group; /* opaque */
+#define GM_GROUP_LOOPBACK (1u << 0) /* ranks may share a device (tests on a 1-GPU box): the records travel by device
+                                       copies instead of RCCL; everything else is the same code */
+gm_status gm_group_create(const gm_config *cfg, const int32_t *devices, uint32_t n_ranks, uint32_t flags, gm_group **out);
+void gm_group_destroy(gm_group *grp);
+uint32_t gm_group_size(const gm_group *grp);
+/* the rank's own context, for the per-rank accessors (gm_get_normals, gm_get_voxel_centroids, ...) */
+gm_ctx *gm_group_ctx(gm_group *grp, uint32_t rank);
+const char *gm_group_last_error(const gm_group *grp); /* grp may be NULL for a failure inside gm_group_create */
+/* One sharded frame, blocking.  cloud must be host rows.  res: the merged frame (n_cropped counts every in-box point
+ * once; eigen results from the summed scatter; plane / cylinder = the vote's winners with their global inlier counts). */
+gm_status gm_group_process_frame(gm_group *grp, const gm_cloud *cloud, gm_frame_result *res);
+/* /choppedCloud of the last sharded frame in the single-GPU order (ascending input row); rows x,y,z,pad(= input row) */
+gm_status gm_group_get_cropped_xyz(gm_group *grp, float *xyzw, uint32_t capacity, uint32_t *n_out);
 
 #ifdef __cplusplus
 }

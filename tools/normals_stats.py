@@ -22,11 +22,11 @@ with g.GeometricMapping(neighborRadius=r, flags=_lib.GM_CFG_DEFAULT | _lib.GM_CF
     rc = lib.gm_debug_counters(c._ctx, 0, out)
     d = list(out)
 n = res["n_cropped"]
-# DevCounters: n_cropped, n_valid, n_tiles (matrix-core list), n_tiles_b (VALU list), n_voxels, vox_n, mm[6], scratch_total, pad[5]
-tiles = d[2] + d[3]
+# DevCounters: n_cropped, n_valid, n_tiles, reserved0, n_voxels, vox_n, mm[6], scratch_total, pad[5]
+tiles = d[2]
 streamed, groupsum, staged, chunks = d[13], d[14], d[15], d[16]
 hits = int(counts.astype(np.int64).sum())
-print(json.dumps({"rc": rc, "impl": os.environ.get("GM_NORMALS_IMPL", "auto"), "n_cropped": n, "tiles": tiles, "tiles_matrix_core": d[2], "tiles_valu": d[3], "lane_fill": n / (64.0 * tiles), "chunks_per_tile": chunks / tiles,
+print(json.dumps({"rc": rc, "impl": os.environ.get("GM_NORMALS_IMPL", "auto"), "n_cropped": n, "tiles": tiles, "tiles_on_valu": d[17], "lane_fill": n / (64.0 * tiles), "chunks_per_tile": chunks / tiles,
                   "mean_neighbours": hits / n, "wave_candidates_per_tile": streamed / tiles,
                   "mean_group_window_per_tile": groupsum / 4 / tiles, "staged_per_tile": staged / tiles,
                   "hit_rate_active_lanes": hits / (streamed * 64.0 * n / (64.0 * tiles)),
