@@ -299,13 +299,18 @@ static void normal_from_neighbours_f64(const float *xyz, const float *q, const n
     out[0] = (float)nx; out[1] = (float)ny; out[2] = (float)nz; out[3] = (float)curv;
 }
 
-static void normal_from_neighbours_f32(const float *xyz, const float *q, nb_t *nb, int m, float *out)
+static void normal_from_neighbours_f32(const float *xyz, const float *q, nb_t *nb, int m, float *out, int shifted)
 {
     qsort(nb, (size_t)m, sizeof(nb_t), nb_cmp);
-    /* PCL 1.8 centroid.hpp: un-shifted single pass, 9 float accumulators */
+    /* PCL 1.8 centroid.hpp: un-shifted single pass, 9 float accumulators.
+     * PCL >= 1.10 centroid.hpp (shifted != 0): the same pass over p - K with K = the neighbourhood's first point
+     * ("shift the data to avoid catastrophic cancellation"); the covariance does not depend on K, only its rounding. */
     float a[9] = {0};
+    float K[3] = {0.0f, 0.0f, 0.0f};
+    if (shifted) { const float *p0 = xyz + 3 * (size_t)nb[0].j; K[0] = p0[0]; K[1] = p0[1]; K[2] = p0[2]; }
     for (int t = 0; t < m; t++) {
-        const float *p = xyz + 3 * (size_t)nb[t].j;
+        const float *pp = xyz + 3 * (size_t)nb[t].j;
+        const float p[3] = {pp[0] - K[0], pp[1] - K[1], pp[2] - K[2]};
         a[0] += p[0] * p[0]; a[1] += p[0] * p[1]; a[2] += p[0] * p[2];
         a[3] += p[1] * p[1]; a[4] += p[1] * p[2]; a[5] += p[2] * p[2];
         a[6] += p[0]; a[7] += p[1]; a[8] += p[2];
@@ -375,8 +380,8 @@ int gmo_normals(const float *xyz, int n, double radius, int mode, int nthreads,
             if (counts_out) counts_out[i] = m;
             if (m < 3 || fail) { /* NormalEstimation::computePointNormal: indices.size()<3 */
                 o[0] = o[1] = o[2] = o[3] = NAN;
-            } else if (mode == GMO_F32_FAITHFUL) {
-                normal_from_neighbours_f32(xyz, q, nb, m, o);
+            } else if (mode == GMO_F32_FAITHFUL || mode == GMO_F32_SHIFTED) {
+                normal_from_neighbours_f32(xyz, q, nb, m, o, mode == GMO_F32_SHIFTED);
             } else {
                 normal_from_neighbours_f64(xyz, q, nb, m, o);
             }
@@ -603,7 +608,7 @@ static void eigen_selfadjoint3_f32(const float Ain[3][3], float *evals, float *e
 void gmo_local_frame(const float *normals, int n, double wf, int mode,
                      double *M_out, float *evals, float *evecs)
 {
-    if (mode == GMO_F32_FAITHFUL) {
+    if (mode == GMO_F32_FAITHFUL || mode == GMO_F32_SHIFTED) {
         float M[3][3] = {{0}};
         for (int i = 0; i < n; i++) {
             const float *nr = normals + 4 * (size_t)i;

@@ -31,6 +31,8 @@ extern "C" {
 /* numeric modes */
 #define GMO_F64 0          /* mathematical truth: same neighbour sets, double sums, Jacobi */
 #define GMO_F32_FAITHFUL 1 /* PCL<=1.9 / Eigen 3.3 fp32 operation order as far as restatable */
+#define GMO_F32_SHIFTED 2  /* as 1, but the PCL >= 1.10 computeMeanAndCovarianceMatrix: fp32 accumulators of the offsets
+                              from the neighbourhood's FIRST point (package.xml pins no PCL version: SURVEY.md par. 8c) */
 
 /* src/tunnel_processing.cpp:39-49 chopCloud -> pcl::CropBox::applyFilter.
  * Keeps i iff !(x<-b || y<-b || z<-b || x>b || y>b || z>b) with b cast to

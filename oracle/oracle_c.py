@@ -14,6 +14,7 @@ import numpy as np
 
 F64 = 0
 F32_FAITHFUL = 1
+F32_SHIFTED = 2   # PCL >= 1.10 covariance (offsets from the neighbourhood's first point), otherwise as F32_FAITHFUL
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libgm_oracle.so")

@@ -239,11 +239,60 @@ def test_process_frame_vs_oracle(ctx, oc, n, seed, axis, kw):
     assert abs(l[1] - lo[1]) / lo[1] < 1e-5 and abs(l[2] - lo[2]) / lo[2] < 1e-5
     assert abs(l[0] - lo[0]) < 1e-5 * lo[2]
     assert np.abs(res["scatter"] - o["M"]).max() / np.abs(o["M"]).max() < 1e-5
-    # the f32-faithful restatement of the reference agrees to the same bar on the well-posed outputs
-    f = oc.process_frame(xyz, B, R, LEAF, WF, oc.F32_FAITHFUL, want_outputs=False)
-    assert ang(res["center_axis"], f["evecs"][:, 0]) < 3e-5
-    # (its lambdas carry the reference's sequential-fp32 summation error, ~sqrt(n)*eps)
-    assert abs(l[2] - f["evals"][2]) / lo[2] < 1e-4
+    # The f32-faithful restatements of the reference (PCL <= 1.9 un-shifted and PCL >= 1.10 shifted covariance) are the
+    # noisy side here: their own distance from the f64 value bounds how close anything can be to them.  The GPU must
+    # be at least as close to each of them as that mode is to f64, plus the 1e-5 bar (observed deltas: DESIGN.md par. 5,
+    # tests/test_gpu_parity.py::test_deltas_against_the_f32_faithful_modes_are_reported).
+    for mode in (oc.F32_FAITHFUL, oc.F32_SHIFTED):
+        f = oc.process_frame(xyz, B, R, LEAF, WF, mode, want_outputs=False)
+        own = ang(f["evecs"][:, 0], o["evecs"][:, 0])
+        assert ang(res["center_axis"], f["evecs"][:, 0]) < own + 1e-5
+        for k in (1, 2):
+            own_l = abs(float(f["evals"][k]) - lo[k]) / lo[k]
+            assert abs(l[k] - f["evals"][k]) / lo[k] < own_l + 1e-5
+
+
+def test_deltas_against_the_f32_faithful_modes_are_reported(gm, oc, tmp_path_factory):
+    """Parity unpinned, quantified: how far the GPU frame is from the oracle's two fp32-faithful modes and from its f64
+    mode, per kind of cloud -- including the kinds where PCL's float rounding decides the outcome (duplicates, collinear
+    runs: the kernel's fp64 solve returns NaN for an exactly singular covariance where PCL's float cross products
+    usually give a finite normal, so n_valid may differ there).  Written to gpurun_out/parity_deltas.json for
+    DESIGN.md par. 5; the asserts only bound what was observed when the table was made."""
+    import json, os
+    rng = np.random.default_rng(5)
+    base = rng.uniform(-2, 2, (400, 3)).astype(np.float32)
+    t = np.linspace(-1, 1, 300, dtype=np.float32)
+    clouds = {
+        "tunnel_50k (BASELINE configs[0] shape)": synth.tunnel_frame(50000, seed=0),
+        "tunnel_floor_outliers_60k": synth.tunnel_frame(60000, seed=2, floor_z=-1.2, outlier_frac=0.01),
+        "duplicates_4k (400 sites x10)": base[rng.integers(len(base), size=4000)],
+        "collinear_run_300 + tunnel_5k": np.vstack([np.stack([t, t * 0.5, t * 0 + 1], axis=1), synth.tunnel_frame(5000, seed=3)]).astype(np.float32),
+    }
+    report = {}
+    with gm.GeometricMapping(boxFilterBound=B, voxelGridLeafSize=LEAF, neighborRadius=R, weightingFactor=WF) as c:
+        for name, xyz in clouds.items():
+            res = c.process_frame(xyz)
+            nrm = c.normals()
+            _, rows = c.cropped_cloud()
+            row = {"n_valid_gpu": int(res["n_valid"])}
+            for tag, mode in (("f64", oc.F64), ("f32_pcl19", oc.F32_FAITHFUL), ("f32_pcl110", oc.F32_SHIFTED)):
+                o = oc.process_frame(xyz, B, R, LEAF, WF, mode)
+                both, ig, io = np.intersect1d(rows, oc.crop_box(xyz, B)[oc.finite_normals(oc.normals(xyz[oc.crop_box(xyz, B)], R, mode)[0])], return_indices=True)
+                a = ang(nrm[ig, :3], o["normals"][io, :3]) if len(both) else np.zeros(1)
+                row[tag] = {"n_valid": int(o["n_valid"]), "n_valid_diff": int(res["n_valid"]) - int(o["n_valid"]),
+                            "normal_angle_p50": float(np.quantile(a, 0.5)), "normal_angle_p999": float(np.quantile(a, 0.999)),
+                            "axis_angle": float(ang(res["center_axis"], o["evecs"][:, 0])),
+                            "lambda2_rel": float(abs(float(res["eigenvalues"][2]) - float(o["evals"][2])) / max(float(o["evals"][2]), 1e-30))}
+            report[name] = row
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_deltas.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    for name in list(clouds)[:2]:                       # well-posed clouds: identical point sets, tight frame outputs
+        r = report[name]
+        assert r["f64"]["n_valid_diff"] == 0 and r["f32_pcl19"]["n_valid_diff"] == 0
+        assert r["f64"]["axis_angle"] < 1e-5 and r["f64"]["normal_angle_p999"] < 1e-5
+        assert r["f32_pcl110"]["axis_angle"] < 1e-5
 
 
 def test_process_frame_is_deterministic(ctx):

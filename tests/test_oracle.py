@@ -321,3 +321,56 @@ def test_sequential_labels_and_refit(oc):
     mom = oc.segment_moments(xyz, nrm, labels, 2)
     ax = oc.refit_axis(mom)
     assert axis_angle(ax, [1, 0, 0]) < 5e-3
+
+
+# ------------------------------------------------------------------ fp32-faithful modes against their numpy twin
+
+@pytest.mark.parametrize("shifted", [False, True])
+def test_f32_faithful_normals_match_the_numpy_float32_twin(oc, shifted):
+    """GMO_F32_FAITHFUL (PCL <= 1.9 un-shifted covariance) and GMO_F32_SHIFTED (PCL >= 1.10) against the separately
+    written numpy float32-scalar twin: neighbour counts exact, every component to 2e-6 where the neighbourhood is not
+    rank deficient (numpy's float32 trigonometry may differ from glibc's by an ulp), curvature to 1e-5 absolute."""
+    from oracle import oracle_np as onp
+    xyz = synth.tunnel_frame(900, seed=7, outlier_frac=0.02)
+    xyz = xyz[np.all(np.abs(xyz) <= 5, axis=1)]
+    r = 0.9
+    mode = oc.F32_SHIFTED if shifted else oc.F32_FAITHFUL
+    cn, cc = oc.normals(xyz, r, mode)
+    tn, tc, _ = onp.normals_f32(xyz, r, shifted=shifted)
+    assert np.array_equal(cc, tc)
+    assert np.array_equal(np.isnan(cn[:, 0]), np.isnan(tn[:, 0]))
+    ok = np.isfinite(cn[:, 0]) & (cc >= 6)
+    assert ok.sum() > 500
+    assert np.abs(cn[ok, :3] - tn[ok, :3]).max() < 2e-6
+    assert np.abs(cn[ok, 3] - tn[ok, 3]).max() < 1e-5
+
+
+def test_shifted_and_unshifted_covariance_agree_with_f64_to_their_own_precision(oc):
+    """PCL-version ambiguity (package.xml pins none): the >= 1.10 shifted sums are ~100x closer to the f64 value than the
+    <= 1.9 un-shifted ones on a cloud a few metres from the origin; both leave the frame-level fit within 1e-5."""
+    xyz = synth.tunnel_frame(20000, seed=8)
+    n64, _ = oc.normals(xyz, 0.5, oc.F64, nthreads=8)
+    n19, _ = oc.normals(xyz, 0.5, oc.F32_FAITHFUL, nthreads=8)
+    n110, _ = oc.normals(xyz, 0.5, oc.F32_SHIFTED, nthreads=8)
+    ok = np.isfinite(n64[:, 0]) & np.isfinite(n19[:, 0]) & np.isfinite(n110[:, 0])
+    e19 = np.abs(n19[ok, 3] - n64[ok, 3]) / n64[ok, 3]
+    e110 = np.abs(n110[ok, 3] - n64[ok, 3]) / n64[ok, 3]
+    assert np.median(e110) < 0.1 * np.median(e19)
+    f64 = oc.process_frame(xyz, 5.0, 0.5, 0.5, 0.2, oc.F64, nthreads=8)
+    for mode in (oc.F32_FAITHFUL, oc.F32_SHIFTED):
+        f = oc.process_frame(xyz, 5.0, 0.5, 0.5, 0.2, mode, nthreads=8)
+        a, b = f["evecs"][:, 0].astype(np.float64), f64["evecs"][:, 0].astype(np.float64)
+        assert np.linalg.norm(np.cross(a, b)) < 1e-5
+        assert abs(f["evals"][2] - f64["evals"][2]) / f64["evals"][2] < 1e-5
+
+
+def test_f32_faithful_local_frame_sums_match_the_numpy_twin_bit_for_bit(oc):
+    from oracle import oracle_np as onp
+    xyz = synth.cylinder_frame(3000, seed=9)
+    nrm, _ = oc.normals(xyz, 0.6, oc.F32_FAITHFUL)
+    nrm = nrm[oc.finite_normals(nrm)]
+    ev, V, M_c = oc.local_frame(nrm, 0.2, oc.F32_FAITHFUL)
+    M_t = onp.local_frame_f32(nrm, 0.2)
+    assert np.array_equal(M_c.astype(np.float32), M_t)          # sequential fp32 sums: same order, same roundings
+    w = np.linalg.eigvalsh(M_t.astype(np.float64))
+    assert np.allclose(ev, w, rtol=2e-6)
