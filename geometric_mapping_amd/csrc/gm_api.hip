@@ -85,6 +85,14 @@ GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, flo
         k = k > 126 ? 126 : (k < -100 ? -100 : k);  // never clamps for the radii radius_ok() admits
         g.r2_scale = ldexpf(1.0f, k);
     }
+    {
+        const float cmax = fmaxf(fmaxf(fabsf(lo_x), fabsf(lo_x + ex)), fmaxf(fmaxf(fabsf(lo_y), fabsf(lo_y + ey)), fmaxf(fabsf(lo_z), fabsf(lo_z + ez))));
+        int e = 0;
+        (void)frexpf(cmax > 1e-30f ? cmax : 1e-30f, &e);   // cmax = m * 2^e, m in [0.5, 1): ulp(cmax) = 2^(e - 24)
+        g.snap = ldexpf(1.0f, e - 24 < -120 ? -120 : e - 24);
+        static const char *bs = getenv("GM_MX_BAND_SCALE");   // experiments only
+        g.band = 2.0e-5f * h * h * (bs ? (float)atof(bs) : 1.0f);
+    }
     return g;
 }
 
@@ -306,7 +314,7 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     }
     record(ctx, sl, 6);
     if (cf.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)) {
-        st = gm_enqueue_ransac(ctx, sl, n);
+        st = gm_enqueue_ransac(ctx, sl, n, nparts);   // its closing launch also finalizes the frame
         if (st != GM_OK) return st;
     }
     if ((cf.flags & GM_CFG_NEAREST) && (cf.flags & GM_CFG_VOXEL_GRID)) {
@@ -315,7 +323,7 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
                        sl.vox_nn, s, sl.vnorm4, sl.vox_nrm4);
     }
     record(ctx, sl, 7);
-    launch_frame_finalize(nparts, sl, s);
+    if (!(cf.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER))) launch_frame_finalize(nparts, sl, s);
     GM_HIP(ctx, hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(FrameOut), hipMemcpyDeviceToHost, s));
     record(ctx, sl, 8);
     GM_HIP(ctx, hipGetLastError());
@@ -445,7 +453,7 @@ gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H)
 
 // sequential multi-model RANSAC over the valid cloud of a frame: plane first (label 1),
 // then cylinder on what is left (label 2), moments + refits per segment
-gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap)
+gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap, uint32_t scatter_rows)
 {
     const gm_config &cf = ctx->cfg;
     const bool do_plane = (cf.flags & GM_CFG_RANSAC_PLANE) != 0, do_cyl = (cf.flags & GM_CFG_RANSAC_CYLINDER) != 0;
@@ -480,7 +488,8 @@ gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap)
     // one pass over the labelled cloud for the moments of both segments; its partials are reduced by the finalizer
     const uint32_t mom_rows = launch_frame_moments(sl.valid4, sl.vnorm4, sl.labels, n_ptr, n_cap, sl.mom_partial, s);
     launch_ext_finalize(sl.hyp_plane, do_plane ? sl.best_plane : nullptr, sl.hyp_cyl, do_cyl ? sl.best_cyl : nullptr,
-                        sl.mom_plane, sl.mom_cyl, &sl.d_out->ext, sl.mom_partial, mom_rows, s);
+                        sl.mom_plane, sl.mom_cyl, &sl.d_out->ext, sl.mom_partial, mom_rows, s, sl.partials, scatter_rows,
+                        sl.ctr, sl.voxp, sl.d_out);
     return GM_OK;
 }
 

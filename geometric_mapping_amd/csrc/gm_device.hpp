@@ -48,6 +48,12 @@ struct GridParams {
     float r2;           // (float)(radius*radius): KdTreeFLANN::radiusSearch's cast
     float r2_scale;     // power of two s with r2 * s ~ 2^100: k_normals evaluates d2 < r2 as clamp01(fma(d2, -s, r2 * s)),
                         // exact because one ulp of a d2 next to r2, times s, is >= 2^76
+    float snap;         // power of two >= one ulp of the largest coordinate of the grid box: tile origins of the
+                        // matrix-core kernel are multiples of it, which makes point - origin exact up to the rounding of a
+                        // radius-sized number
+    float band;         // half-width of the band around r2 inside which the distance MFMA's value does not decide a pair
+                        // (5e-5 * cell edge^2: >= 20x the error measured by tools/microbench/mfma_probe.hip for offsets
+                        // of the size a tile and its windows span)
 };
 
 // Dense voxel table (fast path of the VoxelGrid stage): when the crop box bounds
@@ -343,6 +349,39 @@ __host__ __device__ inline void eig3_sym_eigen_signs(const double a6[6], double 
         const double d = V[3 * c] * (double)Vf[3 * c] + V[3 * c + 1] * (double)Vf[3 * c + 1] + V[3 * c + 2] * (double)Vf[3 * c + 2];
         if (d < 0.0)
             for (int r = 0; r < 3; ++r) V[3 * c + r] = -V[3 * c + r];
+    }
+}
+
+// ---- the frame's closing step: fixed-order reduction of the scatter partials + 3x3 eigen + result record -------------
+// (SelfAdjointEigenSolver, /root/reference src/tunnel_processing.cpp:129-137.)  One 256-thread block; shared by
+// k_frame_finalize and, when a RANSAC model is part of the frame, the tail of k_ext_finalize (one launch less).
+// red: __shared__ double[256 * 6].
+__device__ __forceinline__ void frame_finalize_block(const double *__restrict__ partials, uint32_t nblocks,
+                                                     const DevCounters *__restrict__ ctr,
+                                                     const VoxelParams *__restrict__ voxp, FrameOut *__restrict__ out,
+                                                     double *red)
+{
+    double m[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t b = threadIdx.x; b < nblocks; b += 256)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) m[k] += partials[b * 6 + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[threadIdx.x * 6 + k] = m[k];
+    __syncthreads();
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) red[threadIdx.x * 6 + k] += red[(threadIdx.x + stride) * 6 + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double M[6], w[3], V[9];
+        for (int k = 0; k < 6; ++k) { M[k] = red[k]; out->scatter[k] = M[k]; }
+        eig3_sym_eigen_signs(M, w, V);   // fp64 Jacobi pairs, column signs of Eigen's float tridiagonal-QR solve
+        for (int k = 0; k < 3; ++k) out->evals[k] = (float)w[k];
+        for (int k = 0; k < 9; ++k) out->evecs[k] = (float)V[k];
+        if (ctr) out->ctr = *ctr;
+        if (voxp) out->vox = *voxp;
     }
 }
 

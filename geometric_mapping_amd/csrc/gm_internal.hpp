@@ -147,7 +147,10 @@ uint32_t launch_frame_moments(const float4 *pts, const float4 *nrm, const uint8_
                               uint32_t n_cap, double *partial32, hipStream_t s);
 void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, const float *hyp_cyl,
                          const uint32_t *best_cyl, double *mom_plane, double *mom_cyl, FrameExt *ext,
-                         const double *partial32, uint32_t mom_rows, hipStream_t s);
+                         const double *partial32, uint32_t mom_rows, hipStream_t s,
+                         const double *scatter_partials = nullptr, uint32_t scatter_rows = 0,
+                         const DevCounters *ctr = nullptr, const VoxelParams *voxp = nullptr, FrameOut *frame_out = nullptr);
+gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap, uint32_t scatter_rows);
 // k_nearest.hip
 void launch_nearest(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, const float4 *queries,
                     const uint32_t *nq_ptr, uint32_t nq_cap, unsigned long long *best, int32_t *idx, hipStream_t s,
@@ -159,7 +162,6 @@ gm_status gm_ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes
 gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H);
 gm_status gm_begin_stage(gm_ctx *ctx, Slot *&sl);
 gm_status gm_check_slot(gm_ctx *ctx, uint32_t slot);
-gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap);
 void launch_minmax(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, DevCounters *ctr, hipStream_t s);
 
 }  // namespace gm

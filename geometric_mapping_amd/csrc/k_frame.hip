@@ -140,29 +140,8 @@ __global__ __launch_bounds__(256) void k_frame_finalize(const double *__restrict
                                                         const VoxelParams *__restrict__ voxp,
                                                         FrameOut *__restrict__ out)
 {
-    __shared__ double red[256][6];
-    double m[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t b = threadIdx.x; b < nblocks; b += 256)
-#pragma unroll
-        for (int k = 0; k < 6; ++k) m[k] += partials[b * 6 + k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) red[threadIdx.x][k] = m[k];
-    __syncthreads();
-    for (int stride = 128; stride > 0; stride >>= 1) {
-        if ((int)threadIdx.x < stride)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) red[threadIdx.x][k] += red[threadIdx.x + stride][k];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        double M[6], w[3], V[9];
-        for (int k = 0; k < 6; ++k) { M[k] = red[0][k]; out->scatter[k] = M[k]; }
-        eig3_sym_eigen_signs(M, w, V);   // fp64 Jacobi pairs, column signs of Eigen's float tridiagonal-QR solve
-        for (int k = 0; k < 3; ++k) out->evals[k] = (float)w[k];
-        for (int k = 0; k < 9; ++k) out->evecs[k] = (float)V[k];
-        if (ctr) out->ctr = *ctr;
-        if (voxp) out->vox = *voxp;
-    }
+    __shared__ double red[256 * 6];
+    frame_finalize_block(partials, nblocks, ctr, voxp, out, red);
 }
 
 uint32_t launch_scatter_partials(const float4 *vnorm4, const uint32_t *n_ptr, uint32_t n_cap, double wf, Slot &sl,

@@ -28,6 +28,7 @@
 // Bound: fp32 VALU issue (~21 ops per query-candidate pair), not HBM: every
 // candidate byte is read once per tile and reused by 64 lanes.
 #include <stdlib.h>
+#include <string.h>
 
 #include "gm_internal.hpp"
 
@@ -684,8 +685,10 @@ __device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned c
         }
         // one origin per tile for the moment features: the tile's middle query (any point near the tile will do)
         const int mid = (int)(qn >> 1);
-        const float ox = __builtin_amdgcn_readlane(q.x, mid), oy = __builtin_amdgcn_readlane(q.y, mid),
-                    oz = __builtin_amdgcn_readlane(q.z, mid);
+        // (readlane on the BIT PATTERN: the builtin is integer-typed, a float argument would be converted, i.e. truncated)
+        const float ox = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q.x), mid)),
+                    oy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q.y), mid)),
+                    oz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q.z), mid));
         const float big = g.r2_scale;
         const v2f neg_big = {-big, -big}, r2_big = {g.r2 * big, g.r2 * big};
         const int ngroups = qn > (uint32_t)kMxGroupLanes ? 2 : 1;  // (a second group of repeated queries is skipped)
@@ -782,7 +785,7 @@ __device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned c
                 if (oe > clen) oe = clen;
                 ob &= ~7u;
                 const int steps = oe > ob ? (int)((oe - ob + 15u) >> 4) : 0;  // wave-uniform: the MFMA needs every lane
-#ifdef GM_NORMALS_STATS
+#if defined(GM_NORMALS_STATS) && !defined(GM_MD_DEBUG)
                 if (lane == 0) {
                     atomicAdd(&ctr->pad[0], (uint32_t)(steps * 16) / 2u);  // candidates streamed per query, in 64-query tile units
                     atomicAdd(&ctr->pad[1], (oe > ob ? oe - ob : 0u) * 2u);
@@ -850,6 +853,386 @@ __device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned c
     }
 }
 
+// ---- matrix-core formulation, distances too ("S1") ----------------------------------
+// The neighbour predicate itself moves onto the matrix cores: for a block of 32 candidates and a group of 32 queries
+//     D1[c][q] = |u_c|^2 + |v_q|^2 - 2 u_c . v_q = |c - q|^2,      u = c - o, v = q - o,
+// is one more bf16 product over 24 k-slots (the bf16x3 terms of |u|^2, 1, u on the candidate side against 1, |v|^2,
+// -2 v on the query side; cross terms below 2^-24 of the largest product are dropped).  D1 differs from FLANN's fp32
+// value by ~1e-6 r^2 (tools/microbench/mfma_probe.hip); a pair closer than `band` to the threshold is re-evaluated
+// exactly as FLANN does, everything else is decided by one packed multiply with clamp.  D1 comes out with the query on
+// the lane and 16 candidates in its registers -- exactly the B fragment order the moment MFMA needs, so the weights
+// never leave the registers.  The candidate-side operand of the distance product needs candidate rows with the
+// FEATURE index along k, the moment product feature rows with the CANDIDATE index along k: one feature-major image
+// serves both, the first through gfx950's transposed LDS read (ds_read_b64_tr_b16, tools/microbench/tr_probe.hip).
+// VALU work per pair: ~2.7 operations instead of 5 (and 10.5 in the all-VALU kernel).
+typedef short s4 __attribute__((ext_vector_type(4)));
+constexpr int kMdChunk = 128;                       // candidates staged per chunk (multiple of 8)
+constexpr int kMdSlots = kMdChunk + 24;             // a 32-candidate block may start at slot 120: reads reach slot 151
+constexpr int kMdOctets = kMdSlots / 8;
+constexpr int kMdOctetWords = 33 * 4;               // 31 feature rows (1 + 9 + 18 + 3) + 2 pad rows = 528 B: 132 dwords = 4 mod 32 banks
+constexpr int kMdWaveLdsBytes = (kMdOctets * kMdOctetWords + 16) * 4;
+
+// feature row behind k-slot s of the distance product (candidate side); the query side holds, slot for slot,
+// 1,1,1 | |v|^2 h,m,l | -2v: h,m,l,h,m,h per coordinate | 0
+__device__ __forceinline__ uint32_t md_row_of_slot(int s)
+{
+    if (s < 3) return 28u + (uint32_t)s;            // |u|^2 h, m, l
+    if (s < 6 || s >= 24) return 0u;                // the constant-1 row (query side: |v|^2 terms / zero)
+    const int c = (s - 6) / 6, j = (s - 6) % 6;     // coordinate, position in (h,h,h,m,m,l)
+    return 1u + 3u * (uint32_t)c + (j < 3 ? 0u : (j < 5 ? 1u : 2u));
+}
+// fp32 -> three bf16 bit patterns (exact: 8 + 8 + 8 mantissa bits, truncation)
+__device__ __forceinline__ void md_split3(float a, uint32_t out[3])
+{
+    const uint32_t ah = __float_as_uint(a) & 0xFFFF0000u;
+    const float ra = a - __uint_as_float(ah);
+    const uint32_t am = __float_as_uint(ra) & 0xFFFF0000u;
+    const float sa = ra - __uint_as_float(am);
+    out[0] = ah >> 16; out[1] = am >> 16; out[2] = __float_as_uint(sa) >> 16;
+}
+__device__ __forceinline__ s4 md_tr_read(const unsigned char *p)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)p);
+}
+
+__device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned char *lds, const uint2 tile, uint32_t min_candidates)
+{
+    const float4 *__restrict__ spts4 = A.spts4;
+    const uint32_t *__restrict__ skeys = A.skeys;
+    DevCounters *__restrict__ ctr = A.ctr;
+    const GridParams &g = A.g;
+    const uint2 *__restrict__ row_bounds = A.row_bounds;
+    float4 *__restrict__ normals4 = A.normals4;
+    int32_t *__restrict__ counts = A.counts;
+    const VoxDense &vd = A.vd;
+    VoxCell *__restrict__ vox_table = A.vox_table;
+    (void)ctr;
+    uint32_t *feat = reinterpret_cast<uint32_t *>(lds);    // this wave's slice: feature rows only
+    const int lane = lane_id();
+    const uint32_t n = ctr->n_cropped;
+    const int qsel = lane & 31, half = lane >> 5;
+    // lane roles of the transposed reads that build the distance MFMA's A fragment (see the header of this section)
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tr0 = 16 * ((lane >> 4) & 1);
+    uint32_t rowoff[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) rowoff[t][e] = md_row_of_slot(16 * t + 8 * half + 4 * e + tq) * 16u;
+    const uint32_t tr_lane_off = (uint32_t)((tr0 + 4 * tp) >> 3) * (uint32_t)(kMdOctetWords * 4) + (uint32_t)((tr0 + 4 * tp) & 7) * 2u;
+    {
+        const uint32_t qs = tile.x, qn = tile.y;
+#ifdef GM_NORMALS_TIMELINE
+        const unsigned long long stat_t0 = wall_clock64();
+#else
+        const unsigned long long stat_t0 = 0ull;
+#endif
+        const bool active = (uint32_t)lane < qn;
+        const uint32_t qidx = qs + (active ? (uint32_t)lane : qn - 1u);
+        const float4 q = spts4[qidx];
+        const uint32_t kl = skeys[qidx];
+        const uint32_t ka = __builtin_amdgcn_readfirstlane(kl);
+        const uint32_t row = ka / (uint32_t)g.nx;
+        const int cy = (int)(row % (uint32_t)g.ny), cz = (int)(row / (uint32_t)g.ny);
+        const int fxl = (int)(kl - row * (uint32_t)g.nx);
+        if (__ballot(active && q.x >= vd.own_lo && q.x < vd.own_hi) == 0) {  // halo-only tile (slab sharding)
+            if (active) {
+                const float nanv = __builtin_nanf("");
+                normals4[__float_as_uint(q.w)] = make_float4(nanv, nanv, nanv, nanv);
+                if (counts) counts[__float_as_uint(q.w)] = 0;
+            }
+            return;
+        }
+        // ---- candidate windows: lane i < 18 finds both ends of the window of (row i / 2, group i % 2)
+        uint32_t sb = 0, se = 0;
+        {
+            const int slot = lane < 9 * kMxGroups ? lane : 0;
+            const int r = slot / kMxGroups, gg = slot % kMxGroups;
+            const int lo_fx = __shfl(fxl, gg * kMxGroupLanes, kWave);
+            const int hi_fx = __shfl(fxl, gg * kMxGroupLanes + kMxGroupLanes - 1, kWave);
+            const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
+            if (lane < 9 * kMxGroups && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                const uint32_t nrow = (uint32_t)(zz * g.ny + yy);
+                const uint2 rb = row_bounds[nrow];
+                const uint32_t rbk = nrow * (uint32_t)g.nx;
+                const int xa = lo_fx > g.xreach ? lo_fx - g.xreach : 0;
+                const int xb = hi_fx + g.xreach < g.nx - 1 ? hi_fx + g.xreach : g.nx - 1;
+                const uint32_t key_b = rbk + (uint32_t)xa, key_e = rbk + (uint32_t)xb + 1u;
+                uint32_t lo1 = rb.x, hi1 = rb.y, lo2 = rb.x, hi2 = rb.y;
+                while (lo1 < hi1 || lo2 < hi2) {
+                    const uint32_t m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
+                    const uint32_t k1 = skeys[m1 < n ? m1 : n - 1u], k2 = skeys[m2 < n ? m2 : n - 1u];
+                    if (lo1 < hi1) { if (k1 < key_b) lo1 = m1 + 1u; else hi1 = m1; }
+                    if (lo2 < hi2) { if (k2 < key_e) lo2 = m2 + 1u; else hi2 = m2; }
+                }
+                sb = lo1; se = lo2;
+            }
+        }
+        // Thin neighbourhoods (fewer than min_candidates candidates in the first group's windows) take the direct path
+        // below: nothing to amortise the feature staging over, and the few-point covariances of a sparse cloud are
+        // near-degenerate, where offsets from the query itself (|offset| < r) in fp64 keep more than offsets from a
+        // tile origin through bf16 features do.
+        bool thin;
+        {
+            uint32_t wl = (lane < 9 * kMxGroups && (lane % kMxGroups) == 0) ? se - sb : 0u;
+            wl = (uint32_t)wave_sum((unsigned long long)wl);
+            thin = wl < min_candidates;
+        }
+        // one origin per tile: the tile's middle query snapped to a multiple of g.snap (a power of two >= one ulp of the
+        // largest coordinate): o is then a multiple of every point's ulp, so the offsets c - o and q - o below carry at
+        // most the rounding of a number of size ~r, not of size ~coordinate
+        const int mid = (int)(qn >> 1);
+        const float inv_snap = 1.0f / g.snap;   // exact: powers of two
+        // (readlane on the BIT PATTERN: the builtin is integer-typed, a float argument would be converted, i.e. truncated)
+        const float ox = rintf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q.x), mid)) * inv_snap) * g.snap,
+                    oy = rintf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q.y), mid)) * inv_snap) * g.snap,
+                    oz = rintf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q.z), mid)) * inv_snap) * g.snap;
+        const float big = g.r2_scale;
+        const v2f big2 = {big, big}, r2v = {g.r2, g.r2};
+        const float band = g.band;
+        const int ngroups = qn > (uint32_t)kMxGroupLanes ? 2 : 1;  // (a second group of repeated queries is skipped)
+        f32x16 acc[kMxGroups];
+
+#pragma unroll
+        for (int gi = 0; gi < kMxGroups; ++gi)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[gi][k] = 0.f;
+
+        // the distance MFMA's B operand (queries): per group and K-step, this lane's 8 coefficients of its query
+        //   d2(c, q) = |u|^2 + |v|^2 - 2 u.v,  u = c - o,  v = q - o,   over 24 k-slots (md_row_of_slot)
+        bf16x8 qb[kMxGroups][2];
+        float gq[kMxGroups][3];
+#pragma unroll
+        for (int gi = 0; gi < kMxGroups; ++gi) {
+            gq[gi][0] = __shfl(q.x, gi * kMxGroupLanes + qsel, kWave);
+            gq[gi][1] = __shfl(q.y, gi * kMxGroupLanes + qsel, kWave);
+            gq[gi][2] = __shfl(q.z, gi * kMxGroupLanes + qsel, kWave);
+            const float vx = gq[gi][0] - ox, vy = gq[gi][1] - oy, vz = gq[gi][2] - oz;
+            const float vv = __fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz));
+            uint32_t sv[3], sx[3], sy[3], sz[3];
+            md_split3(vv, sv); md_split3(-2.0f * vx, sx); md_split3(-2.0f * vy, sy); md_split3(-2.0f * vz, sz);
+            const uint32_t one = 0x3F80u;
+            // k-slots 0..31: 1,1,1 | vv h,m,l | x: h,m,l,h,m,h | y: ... | z: ... | 0 x 8   (16-bit patterns)
+            const uint32_t s0[8] = {one, one, one, sv[0], sv[1], sv[2], sx[0], sx[1]};            // slots 0..7
+            const uint32_t s1[8] = {sx[2], sx[0], sx[1], sx[0], sy[0], sy[1], sy[2], sy[0]};      // slots 8..15
+            const uint32_t s2[8] = {sy[1], sy[0], sz[0], sz[1], sz[2], sz[0], sz[1], sz[0]};      // slots 16..23
+            union { bf16x8 v; uint32_t u[4]; } f0, f1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f0.u[j] = half ? (s1[2 * j] | (s1[2 * j + 1] << 16)) : (s0[2 * j] | (s0[2 * j + 1] << 16));
+                f1.u[j] = half ? 0u : (s2[2 * j] | (s2[2 * j + 1] << 16));                        // slots 24..31: zero
+            }
+            qb[gi][0] = f0.v; qb[gi][1] = f1.v;
+        }
+        auto row_begin = [&](int r) -> uint32_t { return __builtin_amdgcn_readlane(sb, r * kMxGroups); };
+        auto row_end = [&](int r) -> uint32_t { return __builtin_amdgcn_readlane(se, r * kMxGroups + ngroups - 1); };
+        int nr = 0;
+        uint32_t nc0 = 0, nlen = 0;
+        auto seek = [&](int r, uint32_t c) {
+            nlen = 0;
+            while (r < 9) {
+                const uint32_t e = row_end(r);
+                if (c < e) { nr = r; nc0 = c; nlen = (e - c < (uint32_t)kMdChunk) ? e - c : (uint32_t)kMdChunk; return; }
+                ++r;
+                if (r < 9) c = row_begin(r);
+            }
+        };
+        if (thin) {
+            // direct path, self-contained: every lane tests its own query against every candidate of the tile's row
+            // ranges (wave-uniform loads straight from the sorted cloud) and sums the offsets from the query in fp64
+            double tm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = 0; r < 9; ++r) {
+                const uint32_t e = row_end(r);
+                for (uint32_t i = row_begin(r); i < e; ++i) {
+                    const float4 c = spts4[i];
+                    const float dx = c.x - q.x, dy = c.y - q.y, dz = c.z - q.z;
+                    // FLANN L2_Simple: every product and sum rounded, in this order; RadiusResultSet: strict d2 < r2
+                    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                    if (d2 < g.r2) {
+                        const double ex = dx, ey = dy, ez = dz;
+                        tm[0] += 1.0; tm[1] += ex; tm[2] += ey; tm[3] += ez;
+                        tm[4] += ex * ex; tm[5] += ex * ey; tm[6] += ex * ez; tm[7] += ey * ey; tm[8] += ey * ez; tm[9] += ez * ez;
+                    }
+                }
+            }
+            const bool vox_ok = emit_normal(active, q, tm, vd, normals4, counts, qn, stat_t0);
+            if (vd.enabled) voxel_sums(vox_ok, q, vd, vox_table);
+            return;
+        }
+        seek(0, row_begin(0));
+        while (nlen) {
+            const int r = nr;
+            const uint32_t c0 = nc0, clen = nlen;
+            wave_lds_fence();  // previous chunk fully consumed
+            // ---- stage the chunk: each lane takes candidate PAIRS (two bf16 of a feature row make one dword)
+#pragma unroll
+            for (int k = 0; k < (kMdChunk + 2 * kWave - 1) / (2 * kWave); ++k) {
+                const uint32_t i = 2u * (uint32_t)lane + (uint32_t)k * 2u * kWave;
+                if (i < clen) {
+                    const bool vb = i + 1u < clen;
+                    const float4 ca = spts4[c0 + i];
+                    float4 cb = ca;
+                    if (vb) cb = spts4[c0 + i + 1u];
+                    const float uxa = ca.x - ox, uya = ca.y - oy, uza = ca.z - oz;
+                    const float uxb = vb ? cb.x - ox : 0.f, uyb = vb ? cb.y - oy : 0.f, uzb = vb ? cb.z - oz : 0.f;
+                    const uint32_t oct = i >> 3;
+                    uint32_t *fo = feat + oct * (uint32_t)kMdOctetWords + ((i & 7u) >> 1);
+                    auto st = [&](int frow, uint32_t v) { fo[frow * 4] = v; };
+                    auto split3 = [&](float a, float b, int frow) {  // exact: 8 + 8 + 8 mantissa bits
+                        const uint32_t ah = __float_as_uint(a) & 0xFFFF0000u, bh = __float_as_uint(b) & 0xFFFF0000u;
+                        st(frow, pack_hi16(bh, ah));
+                        const float ra = a - __uint_as_float(ah), rb = b - __uint_as_float(bh);
+                        const uint32_t am = __float_as_uint(ra) & 0xFFFF0000u, bm = __float_as_uint(rb) & 0xFFFF0000u;
+                        st(frow + 1, pack_hi16(bm, am));
+                        const float sa = ra - __uint_as_float(am), sb2 = rb - __uint_as_float(bm);
+                        st(frow + 2, pack_hi16(__float_as_uint(sb2), __float_as_uint(sa)));
+                    };
+                    st(0, 0x3F803F80u);  // the count row: 1.0 | 1.0
+                    split3(uxa, uxb, 1); split3(uya, uyb, 4); split3(uza, uzb, 7);
+                    const float xxa = uxa * uxa, yya = uya * uya, zza = uza * uza, xxb = uxb * uxb, yyb = uyb * uyb, zzb = uzb * uzb;
+                    split3(xxa, xxb, 10); split3(uxa * uya, uxb * uyb, 13); split3(uxa * uza, uxb * uzb, 16);
+                    split3(yya, yyb, 19); split3(uya * uza, uyb * uzb, 22); split3(zza, zzb, 25);
+                    // |u|^2; a missing second candidate of the pair is "far" (2^100: d2 = 2^100 + ... never within r2)
+                    split3(__fadd_rn(__fadd_rn(xxa, yya), zza), vb ? __fadd_rn(__fadd_rn(xxb, yyb), zzb) : 0x1p100f, 28);
+                }
+            }
+            // slots behind the chunk that a group's last 32-candidate block may still read: far as well (their other rows
+            // are stale but finite, their weights come out 0 like any other far candidate's: no index masks in the loop)
+            {
+                const uint32_t i = ((clen + 1u) & ~1u) + 2u * (uint32_t)lane;
+                if (lane < 16 && i < (uint32_t)kMdSlots)
+                    feat[(i >> 3) * (uint32_t)kMdOctetWords + ((i & 7u) >> 1) + 28u * 4u] = 0x71807180u;   // bf16(2^100) | bf16(2^100)
+            }
+            wave_lds_fence();
+            if (c0 + clen < row_end(r)) seek(r, c0 + clen); else seek(r + 1, r + 1 < 9 ? row_begin(r + 1) : 0u);
+#pragma unroll
+            for (int gi = 0; gi < kMxGroups; ++gi) {
+                if (gi >= ngroups) break;  // wave-uniform
+                // this group's window inside the chunk, start aligned down to an octet
+                const uint32_t mb = __builtin_amdgcn_readlane(sb, r * kMxGroups + gi),
+                               me = __builtin_amdgcn_readlane(se, r * kMxGroups + gi);
+                uint32_t ob = mb > c0 ? mb - c0 : 0u, oe = me > c0 ? me - c0 : 0u;
+                if (ob > clen) ob = clen;
+                if (oe > clen) oe = clen;
+                ob &= ~7u;
+#if defined(GM_NORMALS_STATS) && !defined(GM_MD_DEBUG)
+                if (lane == 0) {
+                    atomicAdd(&ctr->pad[0], (oe > ob ? ((oe - ob + 31u) >> 5) * 32u : 0u) / 2u);  // candidates streamed per query, in 64-query tile units
+                    atomicAdd(&ctr->pad[1], (oe > ob ? oe - ob : 0u) * 2u);
+                    if (gi == 0) { atomicAdd(&ctr->pad[2], clen); atomicAdd(&ctr->pad[3], 1u); }
+                }
+#endif
+                const uint32_t ob8 = ob;   // (aligned down to an octet above)
+                const int nblk = oe > ob8 ? (int)((oe - ob8 + 31u) >> 5) : 0;   // 32-candidate blocks, wave-uniform
+                const unsigned char *fbytes = reinterpret_cast<const unsigned char *>(feat);
+                uint32_t p = ob8;
+                for (int it = 0; it < nblk; ++it, p += 32u) {
+                    const unsigned char *blk = fbytes + (p >> 3) * (uint32_t)(kMdOctetWords * 4);
+                    // ---- distance MFMA: D1[candidate p + r][query] over the 24 k-slots.  A fragment (candidate rows,
+                    // feature k) out of the feature-major image by transposed reads: 4 rows x 16 candidates per read
+                    const unsigned char *ta = blk + tr_lane_off;
+                    union { bf16x8 v; s4 h[2]; } a0, a1;
+                    a0.h[0] = md_tr_read(ta + rowoff[0][0]); a0.h[1] = md_tr_read(ta + rowoff[0][1]);
+                    a1.h[0] = md_tr_read(ta + rowoff[1][0]); a1.h[1] = md_tr_read(ta + rowoff[1][1]);
+                    // moment MFMA's A fragments (feature row qsel, the two quads of k-step s of this lane half)
+                    const unsigned char *ma = blk + (uint32_t)qsel * 16u + 8u * (uint32_t)half;
+                    union { bf16x8 v; uint2 q2[2]; } m0, m1;
+                    m0.q2[0] = *reinterpret_cast<const uint2 *>(ma);
+                    m0.q2[1] = *reinterpret_cast<const uint2 *>(ma + kMdOctetWords * 4);
+                    m1.q2[0] = *reinterpret_cast<const uint2 *>(ma + 2 * kMdOctetWords * 4);
+                    m1.q2[1] = *reinterpret_cast<const uint2 *>(ma + 3 * kMdOctetWords * 4);
+                    f32x16 d1;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) d1[k] = 0.f;
+                    d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, qb[gi][0], d1, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, qb[gi][1], d1, 0, 0, 0);
+                    // ---- weights: 1 where d2 < r2.  d1 is within `band` of FLANN's fp32 value (mfma_probe.hip): outside the
+                    // band the decision is certain; inside it the pair is re-evaluated exactly as FLANN does
+                    v2f wv[8];
+                    float amin = 3.0e38f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const v2f tt = r2v - (v2f){d1[2 * k], d1[2 * k + 1]};
+                        asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(wv[k]) : "v"(tt), "v"(big2));   // clamp01(t * 2^100 / r2)
+                        amin = fminf(fminf(fabsf(tt.x), fabsf(tt.y)), amin);
+                    }
+#ifdef GM_MD_DEBUG   // diagnostic build: error of the distance MFMA against FLANN's fp32 value, every pair
+                    {
+                        const float vx = gq[gi][0] - ox, vy = gq[gi][1] - oy, vz = gq[gi][2] - oz;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const uint32_t rk = (uint32_t)((k & 3) + 8 * (k >> 2) + 4 * half);
+                            if (p + rk < oe) {
+                                const float4 c = spts4[c0 + p + rk];
+                                const float dx = c.x - gq[gi][0], dy = c.y - gq[gi][1], dz = c.z - gq[gi][2];
+                                const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                                const float err = fabsf(d1[k] - d2) / g.r2;
+                                if (d2 < 4.0f * g.r2) {
+                                    atomicMax(&ctr->pad[1], __float_as_uint(err));
+                                    if (err > 1e-5f) atomicAdd(&ctr->pad[2], 1u);
+                                    if (fabsf(d1[k] - d2) > band) {
+                                        atomicAdd(&ctr->pad[0], 1u);
+                                        atomicMax(&ctr->pad[3], (uint32_t)(sqrtf(vx * vx + vy * vy + vz * vz) / sqrtf(g.r2) * 1000.f));
+                                        const float ux = c.x - ox, uy = c.y - oy, uz = c.z - oz;
+                                        atomicMax(&ctr->pad[4], (uint32_t)(sqrtf(ux * ux + uy * uy + uz * uz) / sqrtf(g.r2) * 1000.f));
+                                    }
+                                }
+                            }
+                        }
+                    }
+#endif
+                    if (__ballot(amin < band)) {   // rare: some pair of this block lies inside the band
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const uint32_t rk = (uint32_t)((k & 3) + 8 * (k >> 2) + 4 * half);
+                            const bool need = fabsf(g.r2 - d1[k]) < band;   // (far slots are never inside the band: a real candidate)
+                            if (__ballot(need)) {
+                                if (need) {
+                                    const float4 c = spts4[c0 + p + rk];
+                                    const float dx = c.x - gq[gi][0], dy = c.y - gq[gi][1], dz = c.z - gq[gi][2];
+                                    // FLANN L2_Simple: every product and sum rounded, in this order; strict d2 < r2
+                                    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                                    const float wk = d2 < g.r2 ? 1.0f : 0.0f;
+                                    if (k & 1) wv[k >> 1].y = wk; else wv[k >> 1].x = wk;
+                                }
+                            }
+                        }
+                    }
+                    union { bf16x8 v; uint32_t u[4]; } b0, b1;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        b0.u[k] = pack_hi16(__float_as_uint(wv[k].y), __float_as_uint(wv[k].x));
+                        b1.u[k] = pack_hi16(__float_as_uint(wv[4 + k].y), __float_as_uint(wv[4 + k].x));
+                    }
+                    // ---- moment MFMA: k order of step s = the candidate order of d1's registers 8s .. 8s+7
+                    acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m0.v, b0.v, acc[gi], 0, 0, 0);
+                    acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m1.v, b1.v, acc[gi], 0, 0, 0);
+                }
+            }
+        }
+        // ---- D[row][query]: lane (q, h) of group g holds rows (k & 3) + 8 (k >> 2) + 4 h in acc[g][k].  A lane's home
+        // query is query (lane & 31) of group (lane >> 5): it keeps its own half of that group's rows and swaps the
+        // other group's registers with lane ^ 32 for the missing half.
+        float own[16], got[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            own[k] = half ? acc[1][k] : acc[0][k];
+            const float snd = half ? acc[0][k] : acc[1][k];
+            got[k] = __shfl_xor(snd, 32, kWave);
+        }
+        auto frow = [&](int rr) -> double {  // feature row rr of the home query
+            const int k = 4 * (rr >> 3) + (rr & 3), hh = (rr >> 2) & 1;
+            return (double)((hh == half) ? own[k] : got[k]);
+        };
+        double mom[10];
+        mom[0] = frow(0);
+#pragma unroll
+        for (int m = 0; m < 9; ++m) mom[1 + m] = (frow(1 + 3 * m) + frow(2 + 3 * m)) + frow(3 + 3 * m);
+
+        const bool vox_ok = emit_normal(active, q, mom, vd, normals4, counts, qn, stat_t0);
+        if (vd.enabled) voxel_sums(vox_ok, q, vd, vox_table);
+    }
+}
+
 // ---- the neighbourhood kernel: one launch, one wave per tile, two formulations ------
 // Tiles are assigned by wave id (grid-stride; with the default grid every wave gets at most one tile and its block
 // retires right after).  No block is long-lived: the hardware block scheduler balances the uneven candidate counts and
@@ -883,6 +1266,23 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs
     const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
     for (uint32_t t = wave_id; t < ntiles; t += n_waves)   // every wave reaches the end: the list is final
         normals_tile_mx(A, lds[threadIdx.x / kWave], A.tiles[t], mx_min_candidates);
+}
+
+// distances and moments on the matrix cores
+__global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals_d(NormalsArgs A, uint32_t mx_min_candidates)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][(kMdWaveLdsBytes + 15) / 16 * 16];
+    // slots the staging never writes (past a chunk's end, the two pad rows) are read as MFMA operands whose products are
+    // masked or land in unused result rows: they only have to be FINITE
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(lds[threadIdx.x / kWave]);
+        for (int i = lane_id(); i < kMdWaveLdsBytes / 16; i += kWave) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint32_t ntiles = A.ctr->n_tiles;
+    if (ntiles > A.tiles_cap) ntiles = A.tiles_cap;
+    const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
+    for (uint32_t t = wave_id; t < ntiles; t += n_waves)
+        normals_tile_mxd(A, lds[threadIdx.x / kWave], A.tiles[t], mx_min_candidates);
 }
 
 // the all-VALU formulation of every tile (GM_NORMALS_IMPL=valu: A/B measurements and the cross-check in tests)
@@ -951,7 +1351,10 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     static const char *impl = getenv("GM_NORMALS_IMPL");
     const uint32_t mx_min = !impl ? (uint32_t)kMxMinCandidates : (impl[0] == 'v' ? 0xFFFFFFFFu : (impl[0] == 'm' ? 0u : (uint32_t)kMxMinCandidates));
     hipEventRecord(sl.ev_k0, s);
+    // a trailing 0 (auto0 / mfma0) selects the first matrix-core formulation (moments only; the predicate stays on the VALU)
+    const bool dist_on_mx = !(impl && strchr(impl, '0'));
     if (mx_min == 0xFFFFFFFFu) hipLaunchKernelGGL(k_normals_valu, dim3(nb), dim3(kNrThreads), 0, s, na);
+    else if (dist_on_mx) hipLaunchKernelGGL(k_normals_d, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
     else hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
     hipEventRecord(sl.ev_k1, s);
 }

@@ -559,8 +559,17 @@ __global__ __launch_bounds__(256) void k_frame_moments(const float4 *__restrict_
 __global__ __launch_bounds__(256) void k_ext_finalize(const float *__restrict__ hyp_plane, const uint32_t *__restrict__ best_plane,
                                const float *__restrict__ hyp_cyl, const uint32_t *__restrict__ best_cyl,
                                double *__restrict__ mom_plane, double *__restrict__ mom_cyl,
-                               FrameExt *__restrict__ ext, const double *__restrict__ partial, uint32_t mom_rows)
+                               FrameExt *__restrict__ ext, const double *__restrict__ partial, uint32_t mom_rows,
+                               const double *__restrict__ scatter_partials, uint32_t scatter_rows,
+                               const DevCounters *__restrict__ ctr, const VoxelParams *__restrict__ voxp,
+                               FrameOut *__restrict__ frame_out)
 {
+    // the frame's own closing step rides along (frame pipeline only): one launch instead of two single-block ones
+    if (frame_out) {
+        __shared__ double fred[256 * 6];
+        frame_finalize_block(scatter_partials, scatter_rows, ctr, voxp, frame_out, fred);
+        __syncthreads();
+    }
     if (mom_rows) {
         __shared__ double red[8][32];
         const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
@@ -763,10 +772,11 @@ uint32_t launch_frame_moments(const float4 *pts, const float4 *nrm, const uint8_
 
 void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, const float *hyp_cyl,
                          const uint32_t *best_cyl, double *mom_plane, double *mom_cyl, FrameExt *ext,
-                         const double *partial32, uint32_t mom_rows, hipStream_t s)
+                         const double *partial32, uint32_t mom_rows, hipStream_t s, const double *scatter_partials,
+                         uint32_t scatter_rows, const DevCounters *ctr, const VoxelParams *voxp, FrameOut *frame_out)
 {
     hipLaunchKernelGGL(k_ext_finalize, dim3(1), dim3(256), 0, s, hyp_plane, best_plane, hyp_cyl, best_cyl, mom_plane,
-                       mom_cyl, ext, partial32, mom_rows);
+                       mom_cyl, ext, partial32, mom_rows, scatter_partials, scatter_rows, ctr, voxp, frame_out);
 }
 
 }  // namespace gm

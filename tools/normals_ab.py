@@ -50,6 +50,8 @@ with tempfile.TemporaryDirectory() as d:
         curv = np.abs(na[ok, 3] - nb[ok, 3]) / np.maximum(np.abs(na[ok, 3]), 1e-30)
         out[impl] = dict(tb, speedup=ta["normals_kernel_ms_median"] / tb["normals_kernel_ms_median"],
                          counts_identical=bool(np.array_equal(A["counts"], B["counts"])), nan_pattern_identical=bool(same_nan),
+                         counts_diff={"points": int((A["counts"] != B["counts"]).sum()), "sum_abs": int(np.abs(A["counts"].astype(np.int64) - B["counts"]).sum()),
+                                      "max_abs": int(np.abs(A["counts"].astype(np.int64) - B["counts"]).max()), "signed_sum": int((B["counts"].astype(np.int64) - A["counts"]).sum())},
                          normal_angle_rad={"max": float(ang.max()), "p999": float(np.quantile(ang, 0.999))},
                          curvature_rel={"max": float(curv.max()), "p999": float(np.quantile(curv, 0.999))},
                          scatter_rel=float(np.abs(A["scatter"] - B["scatter"]).max() / np.abs(A["scatter"]).max()),
