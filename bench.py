@@ -336,13 +336,19 @@ def main():
             buf[:] = r16.reshape(-1).view(np.uint8)
             pinned_inputs.append(as_cloud())
         # ---- SURVEY par. 8(d) protocol: one blocking call per frame, median / p10 / p90
+        import ctypes
+        cloud_out = np.empty((n, 4), dtype=np.float32)      # the node's /choppedCloud message buffer, reused per frame
+        cloud_ptr = cloud_out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        n_out = ctypes.c_uint32(0)
+
         def per_frame(inputs, fetch_cloud=False):
             ms = []
             for i in range(3 + args.frames):
                 t0 = time.perf_counter()
                 ctx.process_frame(inputs[i % len(inputs)])
-                if fetch_cloud:
-                    ctx.cropped_cloud()
+                if fetch_cloud:                               # gm_get_cropped_xyz straight into the reused buffer
+                    st = ctx._L.gm_get_cropped_xyz(ctx._ctx, 0, cloud_ptr, n, ctypes.byref(n_out))
+                    assert st == 0, st
                 if i >= 3:
                     ms.append((time.perf_counter() - t0) * 1e3)
             return quantiles(ms, n)
@@ -427,12 +433,12 @@ def main():
                        "voxelGridLeafSize": leaf, "weightingFactor": wf, "mode": mode, "frames_in_flight": n_slots,
                        "ransac_model": "cylinder, H=1024, tau=0.03 (extension)" if ransac_on else "none (reference-faithful path)",
                        "parallelism": f"{mode}x{world}", "collective_backend": args.dist_backend if world > 1 else None},
-            "roofline": {"kernel": os.environ.get("GM_NORMALS_IMPL", "mfma")[0] == "v" and "k_normals" or "k_normals_mx",
+            "roofline": {"kernel": "k_normals",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": k_roof, "avg_launch_ms_in_pipeline": k_ms,
                          "algorithmic_bytes_per_launch": algo_bytes, "issue": valu,
-                         "note": "compute-bound neighbour loop (k~256, predicate on the VALU, moments on the matrix cores): the HBM "
+                         "note": "compute-bound neighbour loop (k~256; neighbour predicate on the VALU, moments on the matrix cores): the HBM "
                                  "fraction is reported as the contract asks, DESIGN.md par. 4 holds its issue-rate roofline. "
                                  "avg_launch_ms = hipEvent bracket with frames one at a time (= rocprofv3 kernel stats of this "
                                  "command); avg_launch_ms_in_pipeline = the same bracket inside the timed region, where the "

@@ -99,7 +99,13 @@ def _preload_hip_runtime():
         spec = None
     if spec is None or not spec.origin:
         return None
-    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    # the same for RCCL (gm_group_*): torch's bundled librccl.so shares no SONAME with /opt/rocm's, so a process could
+    # map both; libgm_hip.so dlopens the one named here (csrc/gm_group.hip)
+    rccl = os.path.join(libdir, "librccl.so")
+    if os.path.exists(rccl):
+        os.environ.setdefault("GM_RCCL_PATH", rccl)
+    path = os.path.join(libdir, "libamdhip64.so")
     if not os.path.exists(path):
         return None
     return C.CDLL(path, mode=C.RTLD_GLOBAL)

@@ -362,6 +362,14 @@ class GeometricMappingGroup:
     loopback=True runs several ranks on one GPU (tests on a 1-GPU box): same code, records travel by device copies."""
 
     def __init__(self, devices, loopback=False, **cfg_kw):
+        if not loopback:
+            # the group loads RCCL (the copy PyTorch bundles when PyTorch is installed: _lib.py).  Observed on ROCm 7.2 /
+            # torch 2.10: a process that initialises RCCL first and imports torch afterwards aborts at interpreter exit
+            # ("double free or corruption"); the other order is clean.  So torch, if present, goes first.
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         self._L = _lib.load()
         cfg = Config()
         self._L.gm_default_config(C.byref(cfg))

@@ -464,14 +464,15 @@ gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap, uint32_t scat
     // the first model of the frame sees every point (labels == nullptr) and its label pass writes the whole
     // label array, so no memset is needed; best_* are always written by the arg-max kernels
     bool first = true;
+    uint32_t mom_rows = 0;
     if (do_plane) {
         uint8_t *lab = first ? nullptr : sl.labels;
         launch_plane_hypotheses(sl.valid4, lab, 0, n_ptr, n_cap, cf.ransac_seed, H, sl.hyp_plane, sl.cnt_plane, s);
         const uint32_t *fsel = nullptr; const int32_t *fcnt = nullptr; uint32_t fk = 0;
         launch_score_preemptive(0, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_plane, sl.band, H, cf.ransac_threshold,
                                 sl.score_partial, sl.cnt_plane, sl.best_plane, true, &fsel, &fcnt, &fk, s);
-        launch_label(0, sl.valid4, sl.labels, 0, 1, n_ptr, n_cap, sl.hyp_plane, sl.band, sl.best_plane,
-                     cf.ransac_threshold, first ? 1 : 0, fsel, fcnt, fk, s);
+        mom_rows = launch_label(0, sl.valid4, sl.labels, 0, 1, n_ptr, n_cap, sl.hyp_plane, sl.band, sl.best_plane,
+                                cf.ransac_threshold, first ? 1 : 0, fsel, fcnt, fk, s, sl.vnorm4, sl.mom_partial);
         first = false;
     }
     if (do_cyl) {
@@ -481,12 +482,12 @@ gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap, uint32_t scat
         const uint32_t *fsel = nullptr; const int32_t *fcnt = nullptr; uint32_t fk = 0;
         launch_score_preemptive(1, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_cyl, sl.band, H, cf.ransac_threshold,
                                 sl.score_partial, sl.cnt_cyl, sl.best_cyl, true, &fsel, &fcnt, &fk, s);
-        launch_label(1, sl.valid4, sl.labels, 0, 2, n_ptr, n_cap, sl.hyp_cyl, sl.band, sl.best_cyl,
-                     cf.ransac_threshold, first ? 1 : 0, fsel, fcnt, fk, s);
+        mom_rows = launch_label(1, sl.valid4, sl.labels, 0, 2, n_ptr, n_cap, sl.hyp_cyl, sl.band, sl.best_cyl,
+                                cf.ransac_threshold, first ? 1 : 0, fsel, fcnt, fk, s, sl.vnorm4, sl.mom_partial);
         first = false;
     }
-    // one pass over the labelled cloud for the moments of both segments; its partials are reduced by the finalizer
-    const uint32_t mom_rows = launch_frame_moments(sl.valid4, sl.vnorm4, sl.labels, n_ptr, n_cap, sl.mom_partial, s);
+    // the label passes left the moments of their segments in sl.mom_partial (one row per block, the same grid for both
+    // models); the finalizer reduces them
     launch_ext_finalize(sl.hyp_plane, do_plane ? sl.best_plane : nullptr, sl.hyp_cyl, do_cyl ? sl.best_cyl : nullptr,
                         sl.mom_plane, sl.mom_cyl, &sl.d_out->ext, sl.mom_partial, mom_rows, s, sl.partials, scatter_rows,
                         sl.ctr, sl.voxp, sl.d_out);

@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 #include <math.h>
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -41,9 +42,12 @@ struct Rccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool load(std::string &err)
     {
-        // a process that already holds an RCCL (e.g. PyTorch's bundled copy) gets that one: same SONAME
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // ONE RCCL per process.  A Python process with PyTorch-ROCm must use the copy PyTorch bundles (it has no SONAME in
+        // common with /opt/rocm's, so the loader would happily map both, and the two tear each other down at exit):
+        // geometric_mapping_amd/_lib.py names it in GM_RCCL_PATH.  A C++ host takes the system library.
+        const char *names[] = {getenv("GM_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char *n : names) {
+            if (!n || !*n) continue;
             handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (handle) break;
         }

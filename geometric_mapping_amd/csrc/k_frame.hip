@@ -147,7 +147,10 @@ __global__ __launch_bounds__(256) void k_frame_finalize(const double *__restrict
 uint32_t launch_scatter_partials(const float4 *vnorm4, const uint32_t *n_ptr, uint32_t n_cap, double wf, Slot &sl,
                                  hipStream_t s)
 {
-    uint32_t nb = (n_cap + 255) / 256;
+    // ~4096 points per block (16 per thread in flight), at least 64 and at most kScatterBlocks blocks: a 1 M-point frame
+    // leaves ~200 partial rows for the single-block finalizer instead of 1024 (its reduction is pure latency)
+    uint32_t nb = (n_cap + 4095) / 4096;
+    if (nb < 64u) nb = (n_cap + 255) / 256 < 64u ? (n_cap + 255) / 256 : 64u;
     if (nb > (uint32_t)kScatterBlocks) nb = kScatterBlocks;
     if (nb == 0) nb = 1;
     hipLaunchKernelGGL(k_scatter_partials, dim3(nb), dim3(256), 0, s, vnorm4, n_ptr, n_cap, .001 / wf, sl.partials);

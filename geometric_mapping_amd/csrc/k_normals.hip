@@ -1268,7 +1268,9 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs
         normals_tile_mx(A, lds[threadIdx.x / kWave], A.tiles[t], mx_min_candidates);
 }
 
-// distances and moments on the matrix cores
+// distances AND moments on the matrix cores (GM_NORMALS_IMPL=auto1 / mfma1): 4 % faster than k_normals with the chip to
+// itself, 5 % slower per step with three frames in flight (its dependent MFMA chains tolerate co-resident kernels
+// worse than k_normals' VALU stream does) -- measured, kept selectable, not the default (DESIGN.md par. 4)
 __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals_d(NormalsArgs A, uint32_t mx_min_candidates)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][(kMdWaveLdsBytes + 15) / 16 * 16];
@@ -1351,8 +1353,8 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     static const char *impl = getenv("GM_NORMALS_IMPL");
     const uint32_t mx_min = !impl ? (uint32_t)kMxMinCandidates : (impl[0] == 'v' ? 0xFFFFFFFFu : (impl[0] == 'm' ? 0u : (uint32_t)kMxMinCandidates));
     hipEventRecord(sl.ev_k0, s);
-    // a trailing 0 (auto0 / mfma0) selects the first matrix-core formulation (moments only; the predicate stays on the VALU)
-    const bool dist_on_mx = !(impl && strchr(impl, '0'));
+    // a trailing 1 (auto1 / mfma1) also moves the neighbour predicate onto the matrix cores (k_normals_d)
+    const bool dist_on_mx = impl && strchr(impl, '1');
     if (mx_min == 0xFFFFFFFFu) hipLaunchKernelGGL(k_normals_valu, dim3(nb), dim3(kNrThreads), 0, s, na);
     else if (dist_on_mx) hipLaunchKernelGGL(k_normals_d, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
     else hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);

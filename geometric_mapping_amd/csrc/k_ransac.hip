@@ -403,13 +403,18 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
 // points (no memset of the label array is needed); otherwise only points with labels == want are touched.
 // counts_k != nullptr: the winner is taken from the K re-scored hypotheses (largest count, lowest hypothesis index
 // on ties) by every block for itself, and block 0 publishes it in best[0..1].
-template <int MODEL>
+// MOM (frame pipeline): the pass also sums the moments of the segment it labels -- count, sum p, sum pp^T and, for the
+// cylinder, sum nn^T, in fp64 -- into mom_partial[block][MODEL * 16 ..]: the points are in registers anyway, so the
+// separate pass over labels + points + normals (33 B per point for 13 algorithmic) is gone; normals are only loaded
+// for inliers.
+template <int MODEL, int MOM>
 __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, uint8_t *__restrict__ labels,
                                                uint32_t want, uint32_t label, const uint32_t *__restrict__ n_ptr,
                                                uint32_t n_host, const float *__restrict__ hyp8,
                                                const float2 *__restrict__ band, uint32_t *__restrict__ best,
                                                float tau, int init, const int32_t *__restrict__ counts_k,
-                                               const uint32_t *__restrict__ sel, uint32_t K)
+                                               const uint32_t *__restrict__ sel, uint32_t K,
+                                               const float4 *__restrict__ nrm, double *__restrict__ mom_partial)
 {
     const uint32_t n = n_ptr ? *n_ptr : n_host;
     uint32_t h;
@@ -431,15 +436,20 @@ __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, u
     } else {
         h = best[0];
     }
+    constexpr int NM = MODEL == 0 ? 10 : 16;
     if (h == 0xFFFFFFFFu) {
         if (init)
             for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) labels[i] = 0;
+        if (MOM && threadIdx.x < 16) mom_partial[(size_t)blockIdx.x * 32 + MODEL * 16 + threadIdx.x] = 0.0;
         return;
     }
     const float *hy = hyp8 + 8 * (size_t)h;
     const float a = hy[0], b = hy[1], c = hy[2], d = hy[3], e = hy[4], f = hy[5];
     float lo2 = 0, hi2 = 0;
     if (MODEL == 1) { const float2 bd = band[h]; lo2 = bd.x; hi2 = bd.y; }
+    double m[NM];
+#pragma unroll
+    for (int k = 0; k < NM; ++k) m[k] = 0.0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (!init && labels[i] != want) continue;
         const float4 p = pts[i];
@@ -447,6 +457,33 @@ __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, u
                                    : cyl_inlier(p.x, p.y, p.z, a, b, c, d, e, f, lo2, hi2);
         if (init) labels[i] = in ? (uint8_t)label : (uint8_t)0;
         else if (in) labels[i] = (uint8_t)label;
+        if (MOM && in) {
+            const double x = p.x, y = p.y, z = p.z;
+            m[0] += 1.0; m[1] += x; m[2] += y; m[3] += z;
+            m[4] += x * x; m[5] += x * y; m[6] += x * z; m[7] += y * y; m[8] += y * z; m[9] += z * z;
+            if (MODEL == 1) {
+                const float4 q = nrm[i];
+                const double u = q.x, v = q.y, w = q.z;
+                m[10] += u * u; m[11] += u * v; m[12] += u * w; m[13] += v * v; m[14] += v * w; m[15] += w * w;
+            }
+        }
+    }
+    if (MOM) {
+        __shared__ double red[256 / kWave][16];
+        const int w = threadIdx.x / kWave;
+#pragma unroll
+        for (int k = 0; k < NM; ++k) {
+            const double r = wave_sum(m[k]);
+            if (lane_id() == 0) red[w][k] = r;
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            double r = 0;
+            if ((int)threadIdx.x < NM)
+#pragma unroll
+                for (int j = 0; j < 256 / kWave; ++j) r += red[j][threadIdx.x];
+            mom_partial[(size_t)blockIdx.x * 32 + MODEL * 16 + threadIdx.x] = r;
+        }
     }
 }
 
@@ -734,20 +771,27 @@ bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels
     return true;
 }
 
-void launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, uint32_t label, const uint32_t *n_ptr,
-                  uint32_t n_cap, const float *hyp8, const float2 *band, uint32_t *best, double tau, int init,
-                  const uint32_t *sel, const int32_t *counts_k, uint32_t K, hipStream_t s)
+uint32_t launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, uint32_t label, const uint32_t *n_ptr,
+                      uint32_t n_cap, const float *hyp8, const float2 *band, uint32_t *best, double tau, int init,
+                      const uint32_t *sel, const int32_t *counts_k, uint32_t K, hipStream_t s, const float4 *nrm,
+                      double *mom_partial)
 {
     // counts_k != nullptr: winner = best of the K (<= 64) finally re-scored hypotheses in (sel[K], counts_k[K])
     uint32_t nb = (n_cap + 255) / 256;
     if (nb > 2048) nb = 2048;
+    if (mom_partial) {   // one partial row per block: ~4096 points per block, at most 512 rows (as k_frame_moments had)
+        nb = (n_cap + 4095) / 4096;
+        if (nb < 64u) nb = (n_cap + 255) / 256 < 64u ? (n_cap + 255) / 256 : 64u;
+        if (nb > (uint32_t)kScatterBlocks / 2) nb = kScatterBlocks / 2;
+    }
     if (nb == 0) nb = 1;
-    if (model == 0)
-        hipLaunchKernelGGL(k_label<0>, dim3(nb), dim3(256), 0, s, pts, labels, want, label, n_ptr, n_cap, hyp8, band,
-                           best, (float)tau, init, counts_k, sel, K);
-    else
-        hipLaunchKernelGGL(k_label<1>, dim3(nb), dim3(256), 0, s, pts, labels, want, label, n_ptr, n_cap, hyp8, band,
-                           best, (float)tau, init, counts_k, sel, K);
+#define GM_LABEL(M, MO)                                                                                                 \
+    hipLaunchKernelGGL((k_label<M, MO>), dim3(nb), dim3(256), 0, s, pts, labels, want, label, n_ptr, n_cap, hyp8, band, \
+                       best, (float)tau, init, counts_k, sel, K, nrm, mom_partial)
+    if (model == 0) { if (mom_partial) GM_LABEL(0, 1); else GM_LABEL(0, 0); }
+    else { if (mom_partial) GM_LABEL(1, 1); else GM_LABEL(1, 0); }
+#undef GM_LABEL
+    return nb;
 }
 
 void launch_segment_moments(const float4 *pts, const float4 *nrm, const uint8_t *labels, uint32_t label,
@@ -763,7 +807,8 @@ void launch_segment_moments(const float4 *pts, const float4 *nrm, const uint8_t 
 uint32_t launch_frame_moments(const float4 *pts, const float4 *nrm, const uint8_t *labels, const uint32_t *n_ptr,
                               uint32_t n_cap, double *partial32, hipStream_t s)
 {
-    uint32_t nb = (n_cap + 255) / 256;
+    uint32_t nb = (n_cap + 4095) / 4096;                             // ~4096 points per block: few partial rows for the finalizer
+    if (nb < 64u) nb = (n_cap + 255) / 256 < 64u ? (n_cap + 255) / 256 : 64u;
     if (nb > (uint32_t)kScatterBlocks / 2) nb = kScatterBlocks / 2;  // partial32 = [kScatterBlocks * 16] doubles = 512 rows
     if (nb == 0) nb = 1;
     hipLaunchKernelGGL(k_frame_moments, dim3(nb), dim3(256), 0, s, pts, nrm, labels, n_ptr, n_cap, partial32);

@@ -477,3 +477,44 @@ def test_frame_smaller_than_capacity_with_another_sort_layout(gm):
         nrm = c.normals()
     assert np.array_equal(res["scatter"], ref["scatter"]) and res["n_valid"] == ref["n_valid"]
     assert np.array_equal(nrm, ref_n, equal_nan=True)
+
+
+@pytest.mark.parametrize("impl", ["valu", "mfma", "auto1", "mfma1"])
+def test_every_formulation_of_the_neighbourhood_kernel_finds_the_same_neighbours(impl):
+    """GM_NORMALS_IMPL (read once per process -> child processes): the all-VALU kernel, the matrix-core kernel forced onto
+    every tile, and the variant that also evaluates the neighbour predicate on the matrix cores (exact re-evaluation
+    inside a band) must report the neighbour counts and NaN pattern of the default build bit for bit, and normals
+    within 1e-5 rad -- on a dense frame and on a sparse one (thin neighbourhoods, long tiles)."""
+    import subprocess, sys, tempfile, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import geometric_mapping_amd as g\n"
+        "from geometric_mapping_amd import _lib, synth\n"
+        "out = {}\n"
+        "for name, xyz, r in (('dense', synth.tunnel_frame(150000, seed=4, floor_z=-1.2, outlier_frac=0.01), 0.3),\n"
+        "                     ('sparse', synth.tunnel_frame(3000, seed=5, outlier_frac=0.05), 0.45)):\n"
+        "    with g.GeometricMapping(neighborRadius=r, flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_KEEP_COUNTS) as c:\n"
+        "        res = c.process_frame(xyz)\n"
+        "        out[name + '_nrm'] = c.normals(); out[name + '_cnt'] = c.neighbor_counts(); out[name + '_sc'] = res['scatter6']\n"
+        "np.savez(sys.argv[1], **out)\n"
+    ) % root
+    got = []
+    with tempfile.TemporaryDirectory() as d:
+        for tag in (None, impl):
+            env = dict(os.environ)
+            env.pop("GM_NORMALS_IMPL", None)
+            if tag:
+                env["GM_NORMALS_IMPL"] = tag
+            f = os.path.join(d, (tag or "default") + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr
+            got.append(dict(np.load(f)))
+    a, b = got
+    for name in ("dense", "sparse"):
+        assert np.array_equal(a[name + "_cnt"], b[name + "_cnt"]), name
+        na, nb = a[name + "_nrm"], b[name + "_nrm"]
+        assert np.array_equal(np.isnan(na), np.isnan(nb))
+        ok = np.isfinite(na[:, 0])
+        assert np.quantile(ang(na[ok, :3], nb[ok, :3]), 0.999) < 1e-5
+        assert np.abs(a[name + "_sc"] - b[name + "_sc"]).max() / np.abs(a[name + "_sc"]).max() < 1e-6
