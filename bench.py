@@ -438,7 +438,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": k_roof, "avg_launch_ms_in_pipeline": k_ms,
                          "algorithmic_bytes_per_launch": algo_bytes, "issue": valu,
-                         "note": "compute-bound neighbour loop (k~256; neighbour predicate on the VALU, moments on the matrix cores): the HBM "
+                         "note": "compute-bound neighbour loop (k~256; distances and moments on the matrix cores, near-threshold pairs re-evaluated exactly on the VALU): the HBM "
                                  "fraction is reported as the contract asks, DESIGN.md par. 4 holds its issue-rate roofline. "
                                  "avg_launch_ms = hipEvent bracket with frames one at a time (= rocprofv3 kernel stats of this "
                                  "command); avg_launch_ms_in_pipeline = the same bracket inside the timed region, where the "

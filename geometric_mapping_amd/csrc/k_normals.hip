@@ -65,7 +65,8 @@ __device__ __forceinline__ v2f pk_within(v2f d2, v2f neg_big, v2f r2_big)
 }
 
 #ifndef GM_NRTHREADS
-#define GM_NRTHREADS 256
+#define GM_NRTHREADS 128   // two tiles per block: small blocks slot in beside the other frames' kernels (measured, 1 M frame,
+                           // three frames in flight: 64 / 128 / 256 / 512 threads = 0.332 / 0.326 / 0.374 / 0.40 ms per step)
 #endif
 constexpr int kNrThreads = GM_NRTHREADS;
 constexpr int kTileQ = kWave;             // queries per tile: one per lane
@@ -1258,7 +1259,7 @@ __device__ __forceinline__ uint32_t normals_wave_id(const NormalsArgs &A, uint32
     return vblock * kNrWaves + threadIdx.x / kWave;
 }
 
-__global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs A, uint32_t mx_min_candidates)
+__global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals_m(NormalsArgs A, uint32_t mx_min_candidates)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][kWaveLdsBytes];
     uint32_t ntiles = A.ctr->n_tiles;   // final before the launch (k_build_tiles)
@@ -1268,10 +1269,9 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs
         normals_tile_mx(A, lds[threadIdx.x / kWave], A.tiles[t], mx_min_candidates);
 }
 
-// distances AND moments on the matrix cores (GM_NORMALS_IMPL=auto1 / mfma1): 4 % faster than k_normals with the chip to
-// itself, 5 % slower per step with three frames in flight (its dependent MFMA chains tolerate co-resident kernels
-// worse than k_normals' VALU stream does) -- measured, kept selectable, not the default (DESIGN.md par. 4)
-__global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals_d(NormalsArgs A, uint32_t mx_min_candidates)
+// THE production kernel: distances AND moments on the matrix cores (k_normals_m = GM_NORMALS_IMPL=auto0 keeps the
+// predicate on the VALU: 13 % slower alone, 4 % slower per step with three frames in flight; DESIGN.md par. 4)
+__global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs A, uint32_t mx_min_candidates)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][(kMdWaveLdsBytes + 15) / 16 * 16];
     // slots the staging never writes (past a chunk's end, the two pad rows) are read as MFMA operands whose products are
@@ -1353,11 +1353,11 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     static const char *impl = getenv("GM_NORMALS_IMPL");
     const uint32_t mx_min = !impl ? (uint32_t)kMxMinCandidates : (impl[0] == 'v' ? 0xFFFFFFFFu : (impl[0] == 'm' ? 0u : (uint32_t)kMxMinCandidates));
     hipEventRecord(sl.ev_k0, s);
-    // a trailing 1 (auto1 / mfma1) also moves the neighbour predicate onto the matrix cores (k_normals_d)
-    const bool dist_on_mx = impl && strchr(impl, '1');
+    // a trailing 0 (auto0 / mfma0) keeps the neighbour predicate on the VALU (k_normals_m: moments only on the matrix cores)
+    const bool dist_on_mx = !(impl && strchr(impl, '0'));
     if (mx_min == 0xFFFFFFFFu) hipLaunchKernelGGL(k_normals_valu, dim3(nb), dim3(kNrThreads), 0, s, na);
-    else if (dist_on_mx) hipLaunchKernelGGL(k_normals_d, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
-    else hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
+    else if (dist_on_mx) hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
+    else hipLaunchKernelGGL(k_normals_m, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
     hipEventRecord(sl.ev_k1, s);
 }
 

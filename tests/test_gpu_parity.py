@@ -479,11 +479,11 @@ def test_frame_smaller_than_capacity_with_another_sort_layout(gm):
     assert np.array_equal(nrm, ref_n, equal_nan=True)
 
 
-@pytest.mark.parametrize("impl", ["valu", "mfma", "auto1", "mfma1"])
+@pytest.mark.parametrize("impl", ["valu", "mfma", "auto0", "mfma0"])
 def test_every_formulation_of_the_neighbourhood_kernel_finds_the_same_neighbours(impl):
-    """GM_NORMALS_IMPL (read once per process -> child processes): the all-VALU kernel, the matrix-core kernel forced onto
-    every tile, and the variant that also evaluates the neighbour predicate on the matrix cores (exact re-evaluation
-    inside a band) must report the neighbour counts and NaN pattern of the default build bit for bit, and normals
+    """GM_NORMALS_IMPL (read once per process -> child processes): the all-VALU kernel, the production kernel (distances
+    and moments on the matrix cores, exact re-evaluation inside a band) forced onto every tile, and the variant that
+    keeps the neighbour predicate on the VALU must report the neighbour counts and NaN pattern of the default build bit for bit, and normals
     within 1e-5 rad -- on a dense frame and on a sparse one (thin neighbourhoods, long tiles)."""
     import subprocess, sys, tempfile, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

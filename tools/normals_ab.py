@@ -27,7 +27,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--points", type=int, default=1_000_000)
 ap.add_argument("--radius", type=float, default=0.0)
 ap.add_argument("--floor", type=int, default=0)
-ap.add_argument("--impls", default="valu,auto,auto1", help="first one is the reference of the comparison")
+ap.add_argument("--impls", default="valu,auto0,auto", help="first one is the reference of the comparison")
 a = ap.parse_args()
 res = {}
 with tempfile.TemporaryDirectory() as d:

@@ -7,6 +7,6 @@ for F in "$@"; do
   touch geometric_mapping_amd/csrc/k_normals.hip
   make -C geometric_mapping_amd/csrc EXTRA="$F" > gpurun_out/sweep_build.log 2>&1 || { echo build failed; tail gpurun_out/sweep_build.log; exit 1; }
   echo "FLAGS [$F]"
-  if [ $first = 1 ]; then impls=valu,auto,auto1; first=0; else impls=auto,auto1; fi
+  if [ $first = 1 ]; then impls=valu,auto0,auto; first=0; else impls=auto0,auto; fi
   timeout -k 10 300 python tools/normals_ab.py --impls $impls 2>&1 | tail -1 || exit 1
 done
