@@ -441,7 +441,7 @@ gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H)
     GM_HIP(ctx, dmalloc(sl.score_partial, (size_t)1024));  // pre-selection scratch (k_ransac.hip kPreScratchWords = 576)
     GM_HIP(ctx, dmalloc(sl.cnt_plane, HH)); GM_HIP(ctx, dmalloc(sl.cnt_cyl, HH));
     GM_HIP(ctx, dmalloc(sl.best_plane, 2)); GM_HIP(ctx, dmalloc(sl.best_cyl, 2));
-    GM_HIP(ctx, dmalloc(sl.mom_partial, (size_t)kScatterBlocks * 16));
+    GM_HIP(ctx, dmalloc(sl.mom_partial, (size_t)kScatterBlocks * 16 * 2));  // [model][row][16]
     GM_HIP(ctx, dmalloc(sl.mom_plane, 16)); GM_HIP(ctx, dmalloc(sl.mom_cyl, 16));
     GM_HIP(ctx, dmalloc(sl.nn_best, sl.cap));
     GM_HIP(ctx, dmalloc(sl.vox_nrm4, sl.cap));

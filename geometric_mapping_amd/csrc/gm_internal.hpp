@@ -144,8 +144,6 @@ uint32_t launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t wa
                       const float4 *nrm = nullptr, double *mom_partial = nullptr);  // returns the grid size (= partial rows)
 void launch_segment_moments(const float4 *pts, const float4 *nrm, const uint8_t *labels, uint32_t label,
                             const uint32_t *n_ptr, uint32_t n_cap, double *partial, double *mom16, hipStream_t s);
-uint32_t launch_frame_moments(const float4 *pts, const float4 *nrm, const uint8_t *labels, const uint32_t *n_ptr,
-                              uint32_t n_cap, double *partial32, hipStream_t s);
 void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, const float *hyp_cyl,
                          const uint32_t *best_cyl, double *mom_plane, double *mom_cyl, FrameExt *ext,
                          const double *partial32, uint32_t mom_rows, hipStream_t s,

@@ -867,7 +867,10 @@ __device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned c
 // serves both, the first through gfx950's transposed LDS read (ds_read_b64_tr_b16, tools/microbench/tr_probe.hip).
 // VALU work per pair: ~2.7 operations instead of 5 (and 10.5 in the all-VALU kernel).
 typedef short s4 __attribute__((ext_vector_type(4)));
-constexpr int kMdChunk = 128;                       // candidates staged per chunk (multiple of 8)
+#ifndef GM_MDCHUNK
+#define GM_MDCHUNK 128
+#endif
+constexpr int kMdChunk = GM_MDCHUNK;                // candidates staged per chunk (multiple of 8)
 constexpr int kMdSlots = kMdChunk + 24;             // a 32-candidate block may start at slot 120: reads reach slot 151
 constexpr int kMdOctets = kMdSlots / 8;
 constexpr int kMdOctetWords = 33 * 4;               // 31 feature rows (1 + 9 + 18 + 3) + 2 pad rows = 528 B: 132 dwords = 4 mod 32 banks

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
 // counts_k != nullptr: the winner is taken from the K re-scored hypotheses (largest count, lowest hypothesis index
 // on ties) by every block for itself, and block 0 publishes it in best[0..1].
 // MOM (frame pipeline): the pass also sums the moments of the segment it labels -- count, sum p, sum pp^T and, for the
-// cylinder, sum nn^T, in fp64 -- into mom_partial[block][MODEL * 16 ..]: the points are in registers anyway, so the
+// cylinder, sum nn^T, in fp64 -- into mom_partial[MODEL][block][16]: the points are in registers anyway, so the
 // separate pass over labels + points + normals (33 B per point for 13 algorithmic) is gone; normals are only loaded
 // for inliers.
 template <int MODEL, int MOM>
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, u
     if (h == 0xFFFFFFFFu) {
         if (init)
             for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) labels[i] = 0;
-        if (MOM && threadIdx.x < 16) mom_partial[(size_t)blockIdx.x * 32 + MODEL * 16 + threadIdx.x] = 0.0;
+        if (MOM && threadIdx.x < 16) mom_partial[((size_t)MODEL * kScatterBlocks + blockIdx.x) * 16 + threadIdx.x] = 0.0;
         return;
     }
     const float *hy = hyp8 + 8 * (size_t)h;
@@ -451,10 +451,10 @@ __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, u
 #pragma unroll
     for (int k = 0; k < NM; ++k) m[k] = 0.0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (!init && labels[i] != want) continue;
+        const bool take = init || labels[i] == want;
         const float4 p = pts[i];
-        const bool in = MODEL == 0 ? plane_inlier(p.x, p.y, p.z, a, b, c, d, tau)
-                                   : cyl_inlier(p.x, p.y, p.z, a, b, c, d, e, f, lo2, hi2);
+        const bool in = take && (MODEL == 0 ? plane_inlier(p.x, p.y, p.z, a, b, c, d, tau)
+                                            : cyl_inlier(p.x, p.y, p.z, a, b, c, d, e, f, lo2, hi2));
         if (init) labels[i] = in ? (uint8_t)label : (uint8_t)0;
         else if (in) labels[i] = (uint8_t)label;
         if (MOM && in) {
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, u
             if ((int)threadIdx.x < NM)
 #pragma unroll
                 for (int j = 0; j < 256 / kWave; ++j) r += red[j][threadIdx.x];
-            mom_partial[(size_t)blockIdx.x * 32 + MODEL * 16 + threadIdx.x] = r;
+            mom_partial[((size_t)MODEL * kScatterBlocks + blockIdx.x) * 16 + threadIdx.x] = r;
         }
     }
 }
@@ -545,54 +545,7 @@ __global__ __launch_bounds__(256) void k_moments_finalize(const double *__restri
 }
 
 // refits + copy of the winning hypotheses into the frame record
-// Frame pipeline: the moments of BOTH segments (label 1 = plane inliers: point moments; label 2 = cylinder inliers:
-// point and normal moments) in one pass over the labelled cloud.  partial rows: [0..15] plane, [16..31] cylinder.
-__global__ __launch_bounds__(256) void k_frame_moments(const float4 *__restrict__ pts, const float4 *__restrict__ nrm,
-                                                       const uint8_t *__restrict__ labels,
-                                                       const uint32_t *__restrict__ n_ptr, uint32_t n_host,
-                                                       double *__restrict__ partial /* [gridDim.x][32] */)
-{
-    __shared__ double red[256 / kWave][32];
-    const uint32_t n = n_ptr ? *n_ptr : n_host;
-    double a[10], b[16];
-#pragma unroll
-    for (int k = 0; k < 10; ++k) a[k] = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) b[k] = 0;
-    // loads are unconditional (label, point, normal: three coalesced streams) so that the unrolled trips keep
-    // twelve loads per lane in flight; only the fp64 accumulation is predicated on the label
-#pragma unroll 4
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t l = labels[i];
-        const float4 p = pts[i];
-        const float4 q = nrm[i];
-        const double x = p.x, y = p.y, z = p.z;
-        if (l == 1u) {
-            a[0] += 1.0; a[1] += x; a[2] += y; a[3] += z;
-            a[4] += x * x; a[5] += x * y; a[6] += x * z; a[7] += y * y; a[8] += y * z; a[9] += z * z;
-        } else if (l == 2u) {
-            const double u = q.x, v = q.y, w = q.z;
-            b[0] += 1.0; b[1] += x; b[2] += y; b[3] += z;
-            b[4] += x * x; b[5] += x * y; b[6] += x * z; b[7] += y * y; b[8] += y * z; b[9] += z * z;
-            b[10] += u * u; b[11] += u * v; b[12] += u * w; b[13] += v * v; b[14] += v * w; b[15] += w * w;
-        }
-    }
-    const int w = threadIdx.x / kWave;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const double ra = k < 10 ? wave_sum(a[k]) : 0.0, rb = wave_sum(b[k]);
-        if (lane_id() == 0) { red[w][k] = ra; red[w][16 + k] = rb; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        double r = 0;
-#pragma unroll
-        for (int j = 0; j < 256 / kWave; ++j) r += red[j][threadIdx.x];
-        partial[(size_t)blockIdx.x * 32 + threadIdx.x] = r;
-    }
-}
-
-// mom_rows > 0: first reduce the k_frame_moments partials (fixed order) into mom_plane / mom_cyl, then finalize.
+// mom_rows > 0: first reduce the label passes' partial rows (fixed order) into mom_plane / mom_cyl, then finalize.
 __global__ __launch_bounds__(256) void k_ext_finalize(const float *__restrict__ hyp_plane, const uint32_t *__restrict__ best_plane,
                                const float *__restrict__ hyp_cyl, const uint32_t *__restrict__ best_cyl,
                                double *__restrict__ mom_plane, double *__restrict__ mom_cyl,
@@ -607,18 +560,19 @@ __global__ __launch_bounds__(256) void k_ext_finalize(const float *__restrict__ 
         frame_finalize_block(scatter_partials, scatter_rows, ctr, voxp, frame_out, fred);
         __syncthreads();
     }
-    if (mom_rows) {
+    if (mom_rows) {   // fixed-order reduction of the label passes' partial rows: partial = [model][kScatterBlocks][16]
         __shared__ double red[8][32];
         const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
+        const double *src = partial + (size_t)(col >> 4) * kScatterBlocks * 16 + (col & 15);
         double r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // four independent chains: the loads of a trip are all in flight together
         uint32_t b = part;
         for (; b + 24 < mom_rows; b += 32) {
-            r0 += partial[(size_t)b * 32 + col];
-            r1 += partial[(size_t)(b + 8) * 32 + col];
-            r2 += partial[(size_t)(b + 16) * 32 + col];
-            r3 += partial[(size_t)(b + 24) * 32 + col];
+            r0 += src[(size_t)b * 16];
+            r1 += src[(size_t)(b + 8) * 16];
+            r2 += src[(size_t)(b + 16) * 16];
+            r3 += src[(size_t)(b + 24) * 16];
         }
-        for (; b < mom_rows; b += 8) r0 += partial[(size_t)b * 32 + col];
+        for (; b < mom_rows; b += 8) r0 += src[(size_t)b * 16];
         red[part][col] = (r0 + r1) + (r2 + r3);
         __syncthreads();
         if (threadIdx.x < 32) {
@@ -779,10 +733,10 @@ uint32_t launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t wa
     // counts_k != nullptr: winner = best of the K (<= 64) finally re-scored hypotheses in (sel[K], counts_k[K])
     uint32_t nb = (n_cap + 255) / 256;
     if (nb > 2048) nb = 2048;
-    if (mom_partial) {   // one partial row per block: ~4096 points per block, at most 512 rows (as k_frame_moments had)
+    if (mom_partial) {   // one partial row per block: ~4096 points per block, at most kScatterBlocks rows
         nb = (n_cap + 4095) / 4096;
         if (nb < 64u) nb = (n_cap + 255) / 256 < 64u ? (n_cap + 255) / 256 : 64u;
-        if (nb > (uint32_t)kScatterBlocks / 2) nb = kScatterBlocks / 2;
+        if (nb > (uint32_t)kScatterBlocks) nb = kScatterBlocks;
     }
     if (nb == 0) nb = 1;
 #define GM_LABEL(M, MO)                                                                                                 \
@@ -802,17 +756,6 @@ void launch_segment_moments(const float4 *pts, const float4 *nrm, const uint8_t 
     if (nb == 0) nb = 1;
     hipLaunchKernelGGL(k_segment_moments, dim3(nb), dim3(256), 0, s, pts, nrm, labels, label, n_ptr, n_cap, partial);
     hipLaunchKernelGGL(k_moments_finalize, dim3(1), dim3(256), 0, s, (const double *)partial, nb, mom16);
-}
-
-uint32_t launch_frame_moments(const float4 *pts, const float4 *nrm, const uint8_t *labels, const uint32_t *n_ptr,
-                              uint32_t n_cap, double *partial32, hipStream_t s)
-{
-    uint32_t nb = (n_cap + 4095) / 4096;                             // ~4096 points per block: few partial rows for the finalizer
-    if (nb < 64u) nb = (n_cap + 255) / 256 < 64u ? (n_cap + 255) / 256 : 64u;
-    if (nb > (uint32_t)kScatterBlocks / 2) nb = kScatterBlocks / 2;  // partial32 = [kScatterBlocks * 16] doubles = 512 rows
-    if (nb == 0) nb = 1;
-    hipLaunchKernelGGL(k_frame_moments, dim3(nb), dim3(256), 0, s, pts, nrm, labels, n_ptr, n_cap, partial32);
-    return nb;
 }
 
 void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, const float *hyp_cyl,

@@ -28,6 +28,10 @@ rows = {
     "gm::k_scatter_partials": ("getLocalFrame sum of (w n)(w n)^T", 16 * n_v, 16 * n_v),
     "gm::k_label<0>": ("plane inlier labelling", 12 * n_v + n_v, 16 * n_v + n_v),
     "gm::k_label<1>": ("cylinder inlier labelling", 12 * n_v + n_v, 16 * n_v + 2 * n_v),
+    # frame pipeline since round 2: the label passes also sum their segment's moments (one pass less over the cloud);
+    # algorithmic = labelling (12 + 1 B per point) + the per-segment covariance (12 B per point, SURVEY par. 8d)
+    "gm::k_label<0, 1>": ("plane inlier labelling + plane-segment moments", 12 * n_v + n_v + 12 * n_v, 16 * n_v + n_v),
+    "gm::k_label<1, 1>": ("cylinder inlier labelling + cylinder-segment moments (normals of the inliers)", 12 * n_v + n_v + 12 * n_v, 16 * n_v + 2 * n_v + 16 * n_v),
     "gm::k_segment_moments": ("per-segment covariance (points + normals of one label)", 24 * n_v + n_v, 32 * n_v + n_v),
     "gm::k_frame_moments": ("per-segment covariance, both segments in one pass (labels + points; normals of cylinder inliers)", 12 * n_v + n_v, 32 * n_v + n_v),
 }
