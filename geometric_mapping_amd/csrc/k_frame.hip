@@ -19,16 +19,8 @@ namespace gm {
 
 // ---- compaction of points with a finite normal ----------------------------------
 struct ValidPred {
-    const float4 *__restrict__ normals4;
-    const float4 *__restrict__ crop4;
-    float own_lo, own_hi;  // slab ownership along x (multi-GPU sharding); +-inf otherwise
-    __device__ __forceinline__ bool operator()(uint32_t i) const
-    {
-        const float4 nn = normals4[i];
-        if (!finite3(nn.x, nn.y, nn.z)) return false;
-        const float x = crop4[i].x;
-        return x >= own_lo && x < own_hi;
-    }
+    const uint8_t *__restrict__ valid8;   // written by k_normals: finite normal && x in the rank's owned range
+    __device__ __forceinline__ bool operator()(uint32_t i) const { return valid8[i] != 0; }
 };
 
 struct ValidEmit {
@@ -92,7 +84,7 @@ void launch_compact_valid(Slot &sl, uint32_t n_cap, float own_lo, float own_hi, 
 {
     const uint32_t nb = compact_blocks(n_cap);
     if (nb == 0) return;
-    ValidPred pred{sl.normals4, sl.crop4, own_lo, own_hi};
+    ValidPred pred{sl.valid8};   // (own_lo / own_hi were applied by k_normals when it wrote the flags)
     ValidEmit emit{sl.normals4, sl.crop4, sl.valid4, sl.vnorm4};
     hipLaunchKernelGGL(k_compact_count<ValidPred>, dim3(nb), dim3(kCpThreads), 0, s, pred,
                        (const uint32_t *)&sl.ctr->n_cropped, 0u, sl.blk);

@@ -23,8 +23,10 @@ for r in csv.DictReader(open(stats)):
 rows = {
     "gm::k_compact_count<gm::CropPred>": ("CropBox predicate pass", 12 * n_in, 12 * n_in),
     "gm::k_compact_scatter<gm::CropPred, gm::CropEmit>": ("CropBox copy (order-preserving)", 12 * n_in + 12 * n_c, 12 * n_in + 16 * n_c + 4 * n_c),
-    "gm::k_compact_count<gm::ValidPred>": ("removeNaNNormals predicate pass", 12 * n_c, 16 * n_c),
-    "gm::k_compact_scatter<gm::ValidPred, gm::ValidEmit>": ("removeNaNNormals + ExtractIndices", 28 * n_c + 28 * n_v, 32 * n_c + 32 * n_v),
+    # since round 2 the predicate is a 1-byte flag per point written by k_normals (the 12 B of the normal it stands for are
+    # counted where they are produced): the count pass streams 1 B per point
+    "gm::k_compact_count<gm::ValidPred>": ("removeNaNNormals predicate pass (1-byte flags)", n_c, n_c),
+    "gm::k_compact_scatter<gm::ValidPred, gm::ValidEmit>": ("removeNaNNormals + ExtractIndices", 28 * n_c + 28 * n_v, n_c + 32 * n_v + 32 * n_v),
     "gm::k_scatter_partials": ("getLocalFrame sum of (w n)(w n)^T", 16 * n_v, 16 * n_v),
     "gm::k_label<0>": ("plane inlier labelling", 12 * n_v + n_v, 16 * n_v + n_v),
     "gm::k_label<1>": ("cylinder inlier labelling", 12 * n_v + n_v, 16 * n_v + 2 * n_v),
