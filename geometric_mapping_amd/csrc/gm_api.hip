@@ -43,12 +43,12 @@ void free_slot_buffers(Slot &sl)
 {
     hipFree(sl.d_raw); hipFree(sl.crop4); hipFree(sl.keys_a); hipFree(sl.keys_b); hipFree(sl.vals_a);
     hipFree(sl.vals_b); hipFree(sl.spts4); hipFree(sl.normals4); hipFree(sl.counts); hipFree(sl.valid4);
-    hipFree(sl.vnorm4); hipFree(sl.tiles); hipFree(sl.row_bounds); hipFree(sl.blk); hipFree(sl.sort.hist); hipFree(sl.seg_start);
+    hipFree(sl.vnorm4); hipFree(sl.tiles); hipFree(sl.row_bounds); hipFree(sl.blk); hipFree(sl.tile_partials); hipFree(sl.sort.hist); hipFree(sl.seg_start);
     hipFree(sl.vox4); hipFree(sl.vox_nn); hipFree(sl.labels); hipFree(sl.valid8);
     if (sl.h_raw) hipHostFree(sl.h_raw);
     sl.d_raw = nullptr; sl.h_raw = nullptr; sl.crop4 = nullptr; sl.keys_a = sl.keys_b = sl.vals_a = sl.vals_b = nullptr;
     sl.spts4 = sl.normals4 = sl.valid4 = sl.vnorm4 = sl.vox4 = nullptr; sl.counts = nullptr; sl.tiles = nullptr; sl.row_bounds = nullptr;
-    sl.blk = nullptr; sl.sort.hist = nullptr; sl.seg_start = nullptr; sl.vox_nn = nullptr; sl.labels = nullptr; sl.valid8 = nullptr;
+    sl.blk = nullptr; sl.tile_partials = nullptr; sl.sort.hist = nullptr; sl.seg_start = nullptr; sl.vox_nn = nullptr; sl.labels = nullptr; sl.valid8 = nullptr;
     sl.cap = 0; sl.raw_cap = 0; sl.tiles_cap = 0;
 }
 
@@ -160,6 +160,7 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
     sl.h_raw = h_raw; sl.d_raw = d_raw; sl.raw_cap = raw_cap;
     uint32_t cap = n + n / 4 + 1024;
     if (cap < ctx->cfg.max_points) cap = ctx->cfg.max_points;
+    cap = (cap + 3u) & ~3u;  // whole 16 B groups of keys (k_rows_and_tiles reads them as uint4)
     GM_HIP(ctx, dmalloc(sl.crop4, cap));
     GM_HIP(ctx, dmalloc(sl.keys_a, cap)); GM_HIP(ctx, dmalloc(sl.keys_b, cap));
     GM_HIP(ctx, dmalloc(sl.vals_a, cap)); GM_HIP(ctx, dmalloc(sl.vals_b, cap));
@@ -172,7 +173,10 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
     GM_HIP(ctx, dmalloc(sl.tiles, sl.tiles_cap));
     GM_HIP(ctx, dmalloc(sl.row_bounds, (size_t)1024 * 1024));  // make_grid caps every axis at 1024 cells
     sl.blk_cap = compact_blocks(cap > kVoxDenseMaxCells ? cap : kVoxDenseMaxCells) + 1;
-    GM_HIP(ctx, dmalloc(sl.blk, sl.blk_cap));
+    GM_HIP(ctx, dmalloc(sl.tile_partials, (size_t)compact_blocks(cap) * 6));
+    GM_HIP(ctx, dmalloc(sl.blk, (size_t)sl.blk_cap));
+    GM_HIP(ctx, hipMemsetAsync(sl.blk, 0, sizeof(unsigned long long) * (size_t)sl.blk_cap, sl.stream));
+    sl.scan_epoch = 0;
     sl.sort.hist_cap = radix_hist_entries(cap);
     GM_HIP(ctx, dmalloc(sl.sort.hist, sl.sort.hist_cap));
     sl.cap = cap;
@@ -299,9 +303,9 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     record(ctx, sl, 2);
     launch_grid_and_normals(g, vd, sl, n, (cf.flags & GM_CFG_KEEP_COUNTS) != 0, true, s);
     record(ctx, sl, 3);  // end of grid+normals; the kernel alone is bracketed by ev_k0/ev_k1
-    launch_compact_valid(sl, n, (float)ctx->own_lo, (float)ctx->own_hi, s);
+    // (getLocalFrame's scatter terms are summed by the compaction: one partial row per kCpTile cropped points)
+    const uint32_t nparts = launch_compact_valid(sl, n, cf.weightingFactor, s);
     record(ctx, sl, 4);
-    const uint32_t nparts = launch_scatter_partials(sl.vnorm4, &sl.ctr->n_valid, n, cf.weightingFactor, sl, s);
     record(ctx, sl, 5);
     sl.vox_sort_path = (cf.flags & GM_CFG_VOXEL_GRID) && !vd.enabled;
     if (cf.flags & GM_CFG_VOXEL_GRID) {
@@ -314,7 +318,7 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     }
     record(ctx, sl, 6);
     if (cf.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)) {
-        st = gm_enqueue_ransac(ctx, sl, n, nparts);   // its closing launch also finalizes the frame
+        st = gm_enqueue_ransac(ctx, sl, n, nparts, kCpTile);   // its closing launch also finalizes the frame
         if (st != GM_OK) return st;
     }
     if ((cf.flags & GM_CFG_NEAREST) && (cf.flags & GM_CFG_VOXEL_GRID)) {
@@ -323,7 +327,8 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
                        sl.vox_nn, s, sl.vnorm4, sl.vox_nrm4);
     }
     record(ctx, sl, 7);
-    if (!(cf.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER))) launch_frame_finalize(nparts, sl, s);
+    if (!(cf.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)))
+        launch_frame_finalize(sl.tile_partials, nparts, kCpTile, sl, s);
     GM_HIP(ctx, hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(FrameOut), hipMemcpyDeviceToHost, s));
     record(ctx, sl, 8);
     GM_HIP(ctx, hipGetLastError());
@@ -445,6 +450,7 @@ gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H)
     GM_HIP(ctx, dmalloc(sl.mom_plane, 16)); GM_HIP(ctx, dmalloc(sl.mom_cyl, 16));
     GM_HIP(ctx, dmalloc(sl.nn_best, sl.cap));
     GM_HIP(ctx, dmalloc(sl.vox_nrm4, sl.cap));
+    GM_HIP(ctx, hipMemset(sl.score_partial, 0, sizeof(uint32_t) * 1024));  // (holds the scoring launches' done-counter)
     GM_HIP(ctx, hipMemset(sl.best_plane, 0xFF, 8));
     GM_HIP(ctx, hipMemset(sl.best_cyl, 0xFF, 8));
     sl.ext_H = HH; sl.ext_cap = sl.cap;
@@ -453,7 +459,7 @@ gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H)
 
 // sequential multi-model RANSAC over the valid cloud of a frame: plane first (label 1),
 // then cylinder on what is left (label 2), moments + refits per segment
-gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap, uint32_t scatter_rows)
+gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap, uint32_t scatter_rows, uint32_t row_tile)
 {
     const gm_config &cf = ctx->cfg;
     const bool do_plane = (cf.flags & GM_CFG_RANSAC_PLANE) != 0, do_cyl = (cf.flags & GM_CFG_RANSAC_CYLINDER) != 0;
@@ -489,7 +495,7 @@ gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap, uint32_t scat
     // the label passes left the moments of their segments in sl.mom_partial (one row per block, the same grid for both
     // models); the finalizer reduces them
     launch_ext_finalize(sl.hyp_plane, do_plane ? sl.best_plane : nullptr, sl.hyp_cyl, do_cyl ? sl.best_cyl : nullptr,
-                        sl.mom_plane, sl.mom_cyl, &sl.d_out->ext, sl.mom_partial, mom_rows, s, sl.partials, scatter_rows,
+                        sl.mom_plane, sl.mom_cyl, &sl.d_out->ext, sl.mom_partial, mom_rows, s, sl.tile_partials, scatter_rows, row_tile,
                         sl.ctr, sl.voxp, sl.d_out);
     return GM_OK;
 }
@@ -804,7 +810,7 @@ gm_status gm_get_normals_stage(gm_ctx *ctx, const float *xyz, uint32_t n, double
     vd_off.own_lo = -std::numeric_limits<float>::infinity();
     vd_off.own_hi = std::numeric_limits<float>::infinity();
     launch_grid_and_normals(g, vd_off, sl, n, (ctx->cfg.flags & GM_CFG_KEEP_COUNTS) != 0, false, sl.stream);
-    launch_compact_valid(sl, n, -std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity(), sl.stream);
+    launch_compact_valid(sl, n, 1.0, sl.stream);  // (the scatter rows it leaves are not used here)
     uint32_t m[2] = {0, 0};
     GM_HIP(ctx, hipMemcpyAsync(m, &sl.ctr->n_cropped, 8, hipMemcpyDeviceToHost, sl.stream));
     GM_HIP(ctx, hipStreamSynchronize(sl.stream));
@@ -833,7 +839,7 @@ gm_status gm_get_local_frame(gm_ctx *ctx, const float *nxyzc, uint32_t n, double
     if (st != GM_OK) return st;
     if (n) GM_HIP(ctx, hipMemcpyAsync(sl.vnorm4, nxyzc, (size_t)n * 16, hipMemcpyHostToDevice, sl.stream));
     const uint32_t np = launch_scatter_partials(sl.vnorm4, nullptr, n, wf, sl, sl.stream);
-    launch_frame_finalize(np, sl, sl.stream);
+    launch_frame_finalize(sl.partials, np, 0, sl, sl.stream);
     GM_HIP(ctx, hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(FrameOut), hipMemcpyDeviceToHost, sl.stream));
     GM_HIP(ctx, hipStreamSynchronize(sl.stream));
     GM_HIP(ctx, hipGetLastError());

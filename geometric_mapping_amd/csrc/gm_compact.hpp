@@ -1,14 +1,29 @@
-// gm_compact.hpp -- order-preserving stream compaction (count -> scan -> scatter).
+// gm_compact.hpp -- order-preserving stream compaction in ONE launch (chained scan, decoupled look-back).
 //
 // Used for the crop box (CropBox keeps survivors in input order,
 // /root/reference src/tunnel_processing.cpp:42-46), the NaN-normal removal
 // (src/tunnel_processing.cpp:74-85) and the voxel segment heads.  Output order
-// is part of the observable result (/choppedCloud point order), so the scan is
-// exact and deterministic: wave ballot + popcount for the rank inside a wave,
-// a 4-entry LDS table for the rank of the wave inside the block, and for the
-// rank of the block the sum of the per-block counts before it, which every
-// scatter block adds up for itself (coalesced reads of a few KB from L2: there
-// is no scan kernel between the two launches; block 0 also publishes the total).
+// is part of the observable result (/choppedCloud point order), so the ranks
+// are exact and deterministic: wave ballot + popcount inside a wave, a small
+// LDS table across the waves of a block, and across tiles a chained scan --
+// a tile's block publishes the number of survivors of the tile as soon as it
+// knows it (AGGREGATE), looks back over the records of the tiles before it until
+// it meets one that already holds an inclusive prefix, and then publishes its
+// own (INCLUSIVE).  The input is read once; there is no count pass and no scan
+// kernel.
+//
+// Progress without a ticket counter: the grid is capped at kCpMaxGrid blocks --
+// no more than fit on the chip together (256 threads, <= 128 VGPRs by the launch
+// bounds, a few hundred bytes of LDS: 4 blocks per CU x 256 CUs) -- and block b
+// takes tiles b, b + grid, b + 2 grid, ...  A block only ever waits for lower
+// tiles; the owner of the lowest unfinished tile waits for nothing, and it is
+// either running or will be given a slot, because this launch can never fill
+// every slot with waiting blocks.  (An atomic ticket per block, the usual
+// alternative, is one same-address atomic per block in front of everything else.)
+// A record is one 64-bit word [epoch:30 | state:2 | value:32] written and read
+// with single agent-scope atomics; the epoch (a per-slot launch counter, never 0)
+// makes the records of earlier launches read as "not there yet", so the array
+// is never cleared (zeroed once at allocation).
 #pragma once
 
 #include "gm_device.hpp"
@@ -17,89 +32,123 @@ namespace gm {
 
 constexpr int kCpThreads = 256;
 constexpr int kCpItems = 8;
-constexpr int kCpTile = kCpThreads * kCpItems;  // points per block
+constexpr int kCpTile = kCpThreads * kCpItems;  // points per tile
+constexpr int kCpWaves = kCpThreads / kWave;
+constexpr uint32_t kCpMaxGrid = 1024;           // co-resident by construction (see above)
 
-inline uint32_t compact_blocks(uint32_t n) { return (n + kCpTile - 1) / kCpTile; }
-
-// Pred: __device__ bool operator()(uint32_t i) const
-template <class Pred>
-__global__ __launch_bounds__(kCpThreads) void k_compact_count(Pred pred, const uint32_t *__restrict__ n_ptr,
-                                                               uint32_t n_host, uint32_t *__restrict__ block_counts)
+inline uint32_t compact_blocks(uint32_t n) { return (n + kCpTile - 1) / kCpTile; }  // tiles of n points
+inline uint32_t compact_grid(uint32_t n)
 {
-    __shared__ uint32_t wsum[kCpThreads / kWave];
-    const uint32_t n = n_ptr ? *n_ptr : n_host;
-    const uint32_t base = blockIdx.x * kCpTile;
-    uint32_t cnt = 0;
-    if (base < n) {
-#pragma unroll
-        for (int j = 0; j < kCpItems; ++j) {
-            uint32_t i = base + j * kCpThreads + threadIdx.x;
-            bool v = (i < n) && pred(i);
-            cnt += (uint32_t)__popcll(__ballot(v));
-        }
-    }
-    if (lane_id() == 0) wsum[threadIdx.x / kWave] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t s = 0;
-#pragma unroll
-        for (int w = 0; w < kCpThreads / kWave; ++w) s += wsum[w];
-        block_counts[blockIdx.x] = s;
-    }
+    const uint32_t t = compact_blocks(n);
+    return t < kCpMaxGrid ? t : kCpMaxGrid;
 }
 
-// Emit: __device__ void operator()(uint32_t src, uint32_t dst) const
-// block_counts[nblocks] come from k_compact_count over the same grid (blocks past n wrote 0).
+// Pred: __device__ bool operator()(uint32_t i) const
+// Emit: __device__ void operator()(uint32_t src, uint32_t dst); static constexpr bool kHasFinish; when true,
+//       __device__ void finish(uint32_t tile) is called by every thread of the block once per tile that held input,
+//       after the tile's last emit (per-tile state lives in the functor; finish() resets it)
+// The element count is *n_ptr (device-resident) or n_host; the grid is compact_grid(capacity).  The number of survivors
+// goes to total_out / total_out2 (either may be null) -- also when it is 0.
 template <class Pred, class Emit>
-__global__ __launch_bounds__(kCpThreads) void k_compact_scatter(Pred pred, Emit emit,
-                                                                 const uint32_t *__restrict__ n_ptr, uint32_t n_host,
-                                                                 const uint32_t *__restrict__ block_counts,
-                                                                 uint32_t nblocks, uint32_t *__restrict__ total_out,
-                                                                 uint32_t *__restrict__ total_out2)
+__global__ __launch_bounds__(kCpThreads, 4) void k_compact(Pred pred, Emit emit, const uint32_t *__restrict__ n_ptr,
+                                                            uint32_t n_host, ScanState st,
+                                                            uint32_t *__restrict__ total_out,
+                                                            uint32_t *__restrict__ total_out2)
 {
-    __shared__ uint32_t wcnt[2][kCpThreads / kWave];
-    __shared__ uint32_t wpre[2][kCpThreads / kWave];
+    constexpr uint64_t kAggregate = 1ull << 32, kInclusive = 2ull << 32;
+    __shared__ uint32_t lb_sum[kCpWaves], lb_state[kCpWaves];
+    __shared__ uint32_t wcnt[2][kCpItems][kCpWaves];
     const uint32_t n = n_ptr ? *n_ptr : n_host;
-    const uint32_t base = blockIdx.x * kCpTile;
-    if (base >= n && blockIdx.x != 0) return;  // uniform per block (block 0 stays: it publishes the total)
-    const int w = threadIdx.x / kWave;
-    // this block's first output slot = number of survivors in the blocks before it; block 0 sums ALL blocks
-    uint32_t before = 0, all = 0;
-    {
-        const uint32_t lim = blockIdx.x == 0 ? nblocks : blockIdx.x;
-        uint32_t part = 0;
-        for (uint32_t i = threadIdx.x; i < lim; i += kCpThreads) part += block_counts[i];
-        const uint32_t ws = (uint32_t)wave_sum((unsigned long long)part);
-        if (lane_id() == 0) wpre[0][w] = ws;
-        __syncthreads();
-        uint32_t t = 0;
-#pragma unroll
-        for (int k = 0; k < kCpThreads / kWave; ++k) t += wpre[0][k];
-        if (blockIdx.x == 0) all = t; else before = t;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (total_out) *total_out = all;
-        if (total_out2) *total_out2 = all;
-    }
-    if (base >= n) return;
-    uint32_t running = before;
-#pragma unroll
-    for (int j = 0; j < kCpItems; ++j) {
-        uint32_t i = base + j * kCpThreads + threadIdx.x;
-        bool v = (i < n) && pred(i);
-        uint64_t mask = __ballot(v);
-        uint32_t lane_rank = (uint32_t)__popcll(mask & lanemask_lt());
-        if (lane_id() == 0) wcnt[j & 1][w] = (uint32_t)__popcll(mask);
-        __syncthreads();
-        uint32_t woff = 0, tot = 0;
-#pragma unroll
-        for (int k = 0; k < kCpThreads / kWave; ++k) {
-            uint32_t c = wcnt[j & 1][k];
-            if (k < w) woff += c;
-            tot += c;
+    const uint32_t ntiles = (n + (uint32_t)kCpTile - 1u) / (uint32_t)kCpTile;
+    const int w = threadIdx.x / kWave, lane = lane_id();
+    const uint64_t tag = (uint64_t)st.epoch << 34;
+    if (n == 0) {  // nothing to do but to say so
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (total_out) *total_out = 0;
+            if (total_out2) *total_out2 = 0;
         }
-        if (v) emit(i, running + woff + lane_rank);
-        running += tot;
+        return;
+    }
+    int buf = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {  // uniform per block
+        const uint32_t base = tile * (uint32_t)kCpTile;
+        uint64_t mask[kCpItems];  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < kCpItems; ++j) {
+            const uint32_t i = base + j * kCpThreads + threadIdx.x;
+            const bool v = (i < n) && pred(i);
+            mask[j] = __ballot(v);
+            if (lane == 0) wcnt[buf][j][w] = (uint32_t)__popcll(mask[j]);
+        }
+        __syncthreads();
+        uint32_t total = 0;
+#pragma unroll
+        for (int j = 0; j < kCpItems; ++j)
+#pragma unroll
+            for (int k = 0; k < kCpWaves; ++k) total += wcnt[buf][j][k];
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&st.status[tile], tag | (tile == 0 ? kInclusive : kAggregate) | total, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        // ---- look back.  The whole block does, one record per thread (tile-1-t): the blocks of a 1 M-point frame all
+        // run at once, so inclusive prefixes are rare when the walk starts and a 64-wide window would need several
+        // dependent round trips through the fabric; 256 records per trip cover a 500 k-point span.
+        uint32_t before = 0;
+        if (tile > 0) {
+            int32_t top = (int32_t)tile - 1;
+            for (;;) {
+                const int32_t idx = top - (int32_t)threadIdx.x;
+                // (tiles "before tile 0" read as an inclusive prefix of 0: the walk always ends there at the latest)
+                const uint64_t sv = idx >= 0 ? __hip_atomic_load(&st.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                             : (tag | kInclusive);
+                const bool ready = (sv >> 34) == (uint64_t)st.epoch && ((sv >> 32) & 3u) != 0u;
+                const bool incl = ready && ((sv >> 32) & 3u) == 2u;
+                const uint64_t im = __ballot(incl), rm = __ballot(ready);
+                // per wave: lanes up to and including its first inclusive record (all lanes if it has none)
+                const int first = im ? (int)__builtin_ctzll(im) : kWave;
+                const uint64_t need = first >= kWave - 1 ? ~0ull : ((2ull << first) - 1ull);
+                const uint32_t part = wave_sum(lane <= first ? (uint32_t)sv : 0u);
+                __syncthreads();  // (the previous trip's readers of lb_* are done)
+                if (lane == 0) { lb_sum[w] = part; lb_state[w] = ((rm & need) != need) ? 2u : (im ? 1u : 0u); }
+                __syncthreads();
+                // walk the waves in order: stop at the first with an inclusive record; a wave before that point that
+                // still misses a record means: look again
+                uint32_t acc = 0;
+                bool retry = false, done = false;
+#pragma unroll
+                for (int k = 0; k < kCpWaves; ++k) {
+                    if (!done && !retry) {
+                        if (lb_state[k] == 2u) retry = true;
+                        else { acc += lb_sum[k]; done = lb_state[k] == 1u; }
+                    }
+                }
+                if (retry) { __builtin_amdgcn_s_sleep(2); continue; }
+                before += acc;
+                if (done) break;
+                top -= kCpThreads;
+            }
+            if (threadIdx.x == 0)
+                __hip_atomic_store(&st.status[tile], tag | kInclusive | (uint64_t)(before + total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (threadIdx.x == 0 && tile == ntiles - 1) {  // the last tile knows the number of survivors
+            if (total_out) *total_out = before + total;
+            if (total_out2) *total_out2 = before + total;
+        }
+        uint32_t running = before;
+#pragma unroll
+        for (int j = 0; j < kCpItems; ++j) {
+            const uint32_t i = base + j * kCpThreads + threadIdx.x;
+            uint32_t woff = 0, tot = 0;
+#pragma unroll
+            for (int k = 0; k < kCpWaves; ++k) {
+                const uint32_t c = wcnt[buf][j][k];
+                if (k < w) woff += c;
+                tot += c;
+            }
+            if ((mask[j] >> lane) & 1ull) emit(i, running + woff + (uint32_t)__popcll(mask[j] & lanemask_lt()));
+            running += tot;
+        }
+        if constexpr (Emit::kHasFinish) emit.finish(tile);
     }
 }
 

@@ -12,6 +12,12 @@ constexpr int kWave = 64;
 // Per-frame device counters.  Zeroed by one hipMemsetAsync at the head of a
 // frame; every data-dependent size of the pipeline lives here so that no stage
 // needs a host round-trip.
+// state of one chained-scan launch (gm_compact.hpp)
+struct ScanState {
+    unsigned long long *status;  // [>= grid size] tile records
+    uint32_t epoch;              // 1 .. 2^30-1, different from the previous launches' on this array
+};
+
 struct DevCounters {
     uint32_t n_cropped;   // points surviving the crop box
     uint32_t n_valid;     // points with a finite normal (and owned, when sharded)
@@ -359,8 +365,14 @@ __host__ __device__ inline void eig3_sym_eigen_signs(const double a6[6], double 
 __device__ __forceinline__ void frame_finalize_block(const double *__restrict__ partials, uint32_t nblocks,
                                                      const DevCounters *__restrict__ ctr,
                                                      const VoxelParams *__restrict__ voxp, FrameOut *__restrict__ out,
-                                                     double *red)
+                                                     double *red, uint32_t row_tile = 0)
 {
+    // row_tile != 0: the rows are the NaN-normal compaction's, one per row_tile cropped points (gm_compact.hpp); tiles
+    // past the end of the cropped cloud wrote none
+    if (row_tile) {
+        const uint32_t rows = (ctr->n_cropped + row_tile - 1u) / row_tile;
+        nblocks = rows < nblocks ? rows : nblocks;
+    }
     double m[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t b = threadIdx.x; b < nblocks; b += 256)
 #pragma unroll

@@ -47,15 +47,17 @@ struct Slot {
     uint2 *tiles = nullptr;
     uint32_t tiles_cap = 0;
     uint2 *row_bounds = nullptr;  // [1024*1024] first / one-past-last sorted position per x-row of the search grid
-    uint32_t *blk = nullptr;      // per-block counts / offsets for the compactions
+    unsigned long long *blk = nullptr;  // tile records of the single-pass compactions 
     uint32_t blk_cap = 0;
+    uint32_t scan_epoch = 0;            // launches of k_compact on this slot so far (see gm_compact.hpp)
     SortScratch sort = {};
     uint32_t *seg_start = nullptr;
     float4 *vox4 = nullptr;       // voxel centroids: x,y,z,count
     VoxCell *vox_table = nullptr; // dense voxel table (fast path)
     uint32_t vox_table_cap = 0;   // cells
     int32_t *vox_nn = nullptr;
-    double *partials = nullptr;   // [kScatterBlocks][6]
+    double *partials = nullptr;   // [kScatterBlocks][6]  (gm_get_local_frame on caller-supplied normals)
+    double *tile_partials = nullptr;  // [compact_blocks(cap)][6]  scatter rows left by the NaN-normal compaction
     uint8_t *labels = nullptr;
     DevCounters *ctr = nullptr;
     VoxelParams *voxp = nullptr;
@@ -78,6 +80,16 @@ struct Slot {
     uint32_t n_in = 0;
     gm_frame_result last = {};
 };
+
+// record array + a fresh epoch for the next k_compact launch on this slot's stream
+inline ScanState next_scan(Slot &sl)
+{
+    sl.scan_epoch = (sl.scan_epoch % 0x3FFFFFFEu) + 1u;  // 1 .. 2^30-2, never 0
+    ScanState st;
+    st.status = sl.blk;
+    st.epoch = sl.scan_epoch;
+    return st;
+}
 
 }  // namespace gm
 
@@ -114,11 +126,13 @@ struct ZeroJobs { void *ptr[4]; uint64_t words8[4]; };
 void launch_zero_fill(const ZeroJobs &jobs, hipStream_t s);
 uint32_t max_tiles(uint32_t n_cap, const GridParams &g);
 // k_frame.hip
-void launch_compact_valid(Slot &sl, uint32_t n_cap, float own_lo, float own_hi, hipStream_t s);
+// NaN-normal compaction; also leaves the scatter-matrix partial rows of the survivors in sl.tile_partials (one per
+// kCpTile cropped points); returns the number of rows launched
+uint32_t launch_compact_valid(Slot &sl, uint32_t n_cap, double weightingFactor, hipStream_t s);
 // scatter partials over vnorm4[0..n); returns the number of partial rows written
 uint32_t launch_scatter_partials(const float4 *vnorm4, const uint32_t *n_ptr, uint32_t n_cap, double wf, Slot &sl,
                                  hipStream_t s);
-void launch_frame_finalize(uint32_t n_partials, Slot &sl, hipStream_t s);
+void launch_frame_finalize(const double *partials, uint32_t n_partials, uint32_t row_tile, Slot &sl, hipStream_t s);
 // k_voxel.hip
 void launch_voxel_grid(Slot &sl, uint32_t n_cap, float leaf, int key_bits, hipStream_t s);
 void launch_voxel_dense_finalize(const VoxDense &vd, Slot &sl, hipStream_t s);
@@ -148,9 +162,9 @@ void launch_segment_moments(const float4 *pts, const float4 *nrm, const uint8_t 
 void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, const float *hyp_cyl,
                          const uint32_t *best_cyl, double *mom_plane, double *mom_cyl, FrameExt *ext,
                          const double *partial32, uint32_t mom_rows, hipStream_t s,
-                         const double *scatter_partials = nullptr, uint32_t scatter_rows = 0,
+                         const double *scatter_partials = nullptr, uint32_t scatter_rows = 0, uint32_t row_tile = 0,
                          const DevCounters *ctr = nullptr, const VoxelParams *voxp = nullptr, FrameOut *frame_out = nullptr);
-gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap, uint32_t scatter_rows);
+gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap, uint32_t scatter_rows, uint32_t row_tile);
 // k_nearest.hip
 void launch_nearest(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, const float4 *queries,
                     const uint32_t *nq_ptr, uint32_t nq_cap, unsigned long long *best, int32_t *idx, hipStream_t s,

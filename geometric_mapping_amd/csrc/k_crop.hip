@@ -4,9 +4,9 @@
 //
 // Replaces pcl::fromROSMsg (/root/reference src/geometric_mapping.cpp:55) and
 // chopCloud -> pcl::CropBox (/root/reference src/tunnel_processing.cpp:39-49).
-// HBM-bound: reads point_step bytes per input row (twice: count + scatter, the
-// second pass hits the 256 MiB Infinity Cache for frames below ~10 M points),
-// writes 16 + 4 bytes per survivor.
+// HBM-bound: one launch (chained scan, gm_compact.hpp) reads point_step bytes per
+// input row -- the survivors' rows a second time out of L2 when they are written --
+// and writes 16 + 4 bytes per survivor.
 #include "gm_compact.hpp"
 #include "gm_internal.hpp"
 
@@ -58,6 +58,7 @@ struct CropPred {
 };
 
 struct CropEmit {
+    static constexpr bool kHasFinish = false;
     RowReader rd;
     GridParams g;
     float4 *__restrict__ crop4;
@@ -99,10 +100,8 @@ void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const Gr
     RowReader rd{rows};
     CropPred pred{rd, lo, hi};
     CropEmit emit{rd, g, sl.crop4, sl.keys_a};
-    hipLaunchKernelGGL(k_compact_count<CropPred>, dim3(nb), dim3(kCpThreads), 0, s, pred,
-                       (const uint32_t *)nullptr, n, sl.blk);
-    hipLaunchKernelGGL((k_compact_scatter<CropPred, CropEmit>), dim3(nb), dim3(kCpThreads), 0, s, pred, emit,
-                       (const uint32_t *)nullptr, n, (const uint32_t *)sl.blk, nb, &sl.ctr->n_cropped, (uint32_t *)nullptr);
+    hipLaunchKernelGGL((k_compact<CropPred, CropEmit>), dim3(compact_grid(n)), dim3(kCpThreads), 0, s, pred, emit,
+                       (const uint32_t *)nullptr, n, next_scan(sl), &sl.ctr->n_cropped, (uint32_t *)nullptr);
 }
 
 }  // namespace gm

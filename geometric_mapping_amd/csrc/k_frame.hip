@@ -23,15 +23,61 @@ struct ValidPred {
     __device__ __forceinline__ bool operator()(uint32_t i) const { return valid8[i] != 0; }
 };
 
+// one term of getLocalFrame's scatter matrix (src/tunnel_processing.cpp:100-124) added to m[6]
+__device__ __forceinline__ void scatter_term(const float4 v /* nx,ny,nz,curvature */, double k_wf, double m[6])
+{
+    // :106: float + double -> double, pow(.,2), exp, store to float
+    const double t = (double)v.w + k_wf;
+    const float wgt = (float)exp(t * t);
+    // :119 weights*normals: one fp32 product per component (zeros add exactly)
+    const double a = (double)(wgt * v.x), b = (double)(wgt * v.y), c = (double)(wgt * v.z);
+    // :124 exact fp64 products of those fp32 values
+    m[0] += a * a; m[1] += a * b; m[2] += a * c; m[3] += b * b; m[4] += b * c; m[5] += c * c;
+}
+
+// block sum of m[6] in a fixed order -> row[0..6)
+__device__ __forceinline__ void scatter_row_store(const double m[6], double *__restrict__ row)
+{
+    __shared__ double red[256 / kWave][6];
+    const int w = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double r = wave_sum(m[k]);
+        if (lane_id() == 0) red[w][k] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double r = 0;
+#pragma unroll
+        for (int j = 0; j < 256 / kWave; ++j) r += red[j][threadIdx.x];
+        row[threadIdx.x] = r;
+    }
+}
+
+// The compaction's emit step also accumulates the survivors' scatter terms -- the normals are in registers anyway -- and
+// leaves one partial row per tile (index = tile, i.e. position order: the rows do not depend on which block ran which
+// tile), so getLocalFrame needs no pass of its own over the compacted normals.
 struct ValidEmit {
+    static constexpr bool kHasFinish = true;
     const float4 *__restrict__ normals4;
     const float4 *__restrict__ crop4;
     float4 *__restrict__ valid4;
     float4 *__restrict__ vnorm4;
-    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst) const
+    double k_wf;                     // .001 / weightingFactor
+    double *__restrict__ partials;   // [tiles][6]
+    double m[6];
+    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst)
     {
         valid4[dst] = crop4[src];
-        vnorm4[dst] = normals4[src];
+        const float4 v = normals4[src];
+        vnorm4[dst] = v;
+        scatter_term(v, k_wf, m);
+    }
+    __device__ __forceinline__ void finish(uint32_t tile)
+    {
+        scatter_row_store(m, partials + (size_t)tile * 6);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) m[k] = 0;   // the block's next tile starts afresh
     }
 };
 
@@ -80,16 +126,15 @@ void launch_minmax(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, Dev
     hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(256), 0, s, pts, n_ptr, n_cap, ctr);
 }
 
-void launch_compact_valid(Slot &sl, uint32_t n_cap, float own_lo, float own_hi, hipStream_t s)
+uint32_t launch_compact_valid(Slot &sl, uint32_t n_cap, double wf, hipStream_t s)
 {
     const uint32_t nb = compact_blocks(n_cap);
-    if (nb == 0) return;
-    ValidPred pred{sl.valid8};   // (own_lo / own_hi were applied by k_normals when it wrote the flags)
-    ValidEmit emit{sl.normals4, sl.crop4, sl.valid4, sl.vnorm4};
-    hipLaunchKernelGGL(k_compact_count<ValidPred>, dim3(nb), dim3(kCpThreads), 0, s, pred,
-                       (const uint32_t *)&sl.ctr->n_cropped, 0u, sl.blk);
-    hipLaunchKernelGGL((k_compact_scatter<ValidPred, ValidEmit>), dim3(nb), dim3(kCpThreads), 0, s, pred, emit,
-                       (const uint32_t *)&sl.ctr->n_cropped, 0u, (const uint32_t *)sl.blk, nb, &sl.ctr->n_valid, &sl.ctr->vox_n);
+    if (nb == 0) return 0;
+    ValidPred pred{sl.valid8};   // (the rank's owned range was applied by k_normals when it wrote the flags)
+    ValidEmit emit{sl.normals4, sl.crop4, sl.valid4, sl.vnorm4, .001 / wf, sl.tile_partials, {0, 0, 0, 0, 0, 0}};
+    hipLaunchKernelGGL((k_compact<ValidPred, ValidEmit>), dim3(compact_grid(n_cap)), dim3(kCpThreads), 0, s, pred, emit,
+                       (const uint32_t *)&sl.ctr->n_cropped, 0u, next_scan(sl), &sl.ctr->n_valid, &sl.ctr->vox_n);
+    return nb;  // partial rows: one per tile that held input (the finalizer derives how many from n_cropped)
 }
 
 // ---- scatter matrix: streaming pass ---------------------------------------------
@@ -98,42 +143,21 @@ __global__ __launch_bounds__(256) void k_scatter_partials(const float4 *__restri
                                                           double k_wf /* .001 / weightingFactor */,
                                                           double *__restrict__ partials)
 {
-    __shared__ double red[256 / kWave][6];
     const uint32_t n = n_ptr ? *n_ptr : n_host;
     double m[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 v = vnorm4[i];  // one coalesced 16 B load per lane: nx,ny,nz,curvature
-        // src/tunnel_processing.cpp:106: float + double -> double, pow(.,2), exp, store to float
-        const double t = (double)v.w + k_wf;
-        const float wgt = (float)exp(t * t);
-        // :119 weights*normals: one fp32 product per component (zeros add exactly)
-        const double a = (double)(wgt * v.x), b = (double)(wgt * v.y), c = (double)(wgt * v.z);
-        // :124 exact fp64 products of those fp32 values
-        m[0] += a * a; m[1] += a * b; m[2] += a * c; m[3] += b * b; m[4] += b * c; m[5] += c * c;
-    }
-    const int w = threadIdx.x / kWave;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const double r = wave_sum(m[k]);
-        if (lane_id() == 0) red[w][k] = r;
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        double r = 0;
-#pragma unroll
-        for (int j = 0; j < 256 / kWave; ++j) r += red[j][threadIdx.x];
-        partials[blockIdx.x * 6 + threadIdx.x] = r;
-    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        scatter_term(vnorm4[i], k_wf, m);  // one coalesced 16 B load per lane: nx,ny,nz,curvature
+    scatter_row_store(m, partials + (size_t)blockIdx.x * 6);
 }
 
 // ---- fixed-order reduction of the block partials + 3x3 eigen (one block) ---------
 __global__ __launch_bounds__(256) void k_frame_finalize(const double *__restrict__ partials, uint32_t nblocks,
                                                         const DevCounters *__restrict__ ctr,
                                                         const VoxelParams *__restrict__ voxp,
-                                                        FrameOut *__restrict__ out)
+                                                        FrameOut *__restrict__ out, uint32_t row_tile)
 {
     __shared__ double red[256 * 6];
-    frame_finalize_block(partials, nblocks, ctr, voxp, out, red);
+    frame_finalize_block(partials, nblocks, ctr, voxp, out, red, row_tile);
 }
 
 uint32_t launch_scatter_partials(const float4 *vnorm4, const uint32_t *n_ptr, uint32_t n_cap, double wf, Slot &sl,
@@ -149,10 +173,10 @@ uint32_t launch_scatter_partials(const float4 *vnorm4, const uint32_t *n_ptr, ui
     return nb;
 }
 
-void launch_frame_finalize(uint32_t n_partials, Slot &sl, hipStream_t s)
+void launch_frame_finalize(const double *partials, uint32_t n_partials, uint32_t row_tile, Slot &sl, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_frame_finalize, dim3(1), dim3(256), 0, s, (const double *)sl.partials, n_partials,
-                       (const DevCounters *)sl.ctr, (const VoxelParams *)sl.voxp, sl.d_out);
+    hipLaunchKernelGGL(k_frame_finalize, dim3(1), dim3(256), 0, s, partials, n_partials,
+                       (const DevCounters *)sl.ctr, (const VoxelParams *)sl.voxp, sl.d_out, row_tile);
 }
 
 }  // namespace gm

@@ -83,86 +83,183 @@ constexpr int kWinPad = 16;               // far-away padding behind a chunk (al
 constexpr int kTileSpan = 3;              // max x extent of one tile, in (coarse) cell edges
 constexpr int kNrWaves = kNrThreads / kWave;
 
-// ---- gather the cropped cloud into cell-sorted order ---------------------------
-__global__ __launch_bounds__(256) void k_gather_sorted(const float4 *__restrict__ crop4,
-                                                       const uint32_t *__restrict__ perm,
-                                                       const uint32_t *__restrict__ skeys,
-                                                       const uint32_t *__restrict__ n_ptr, uint32_t nx,
-                                                       float4 *__restrict__ spts4,
-                                                       uint2 *__restrict__ row_bounds /* [ny*nz]: begin, end */)
+// ---- sorted cloud, per-row table and tiles in one launch -------------------------
+// Two roles share the launch (odd / even blocks, so both are in flight together), each block covering kTbSpan sorted
+// positions: odd blocks gather the cropped points into sorted order (a stream of dependent random reads with nothing
+// to synchronise: in one block with the other role each barrier would wait for these loads), even blocks
+//  * publish the first / one-past-last sorted position of every occupied x-row (only occupied rows are ever read),
+//  * cut tiles: <= 64 consecutive sorted points of one x-row spanning <= span+1 cells.  Tiles are cut at every 64th
+//    point counted from the start of the x-row (so dense rows give full tiles: ~90 % lane fill) and a 64-chunk that
+//    spans more than `span` cell steps (sparse rows) is cut again at aligned (span+1)-cell groups, which bounds the
+//    candidate count of a tile: without the bound a sparse row yields tiles 20x the mean that the whole grid waits for.
+// The start of a point's row is the nearest row start at or before it: inside the block a running maximum over the
+// start flags; for the row that is already running when the block begins, the block walks the sorted keys backwards
+// (kTbSpan positions per step) -- no table written by another block is read, so nothing has to precede this launch.
+// A thread owns kTbPer CONSECUTIVE positions (one 16 B key load): the block's chain of barrier-separated steps
+// (~10 us of latency) is paid once per 4096 positions and a 1 M-point frame is one round of resident blocks.
+constexpr int kTbThreads = 1024;
+constexpr int kTbPer = 4;
+constexpr int kTbSpan = kTbThreads * kTbPer;
+__global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const float4 *__restrict__ crop4,
+                                                               const uint32_t *__restrict__ perm,
+                                                               const uint32_t *__restrict__ skeys,
+                                                               DevCounters *__restrict__ ctr, uint32_t nx, uint32_t span,
+                                                               float4 *__restrict__ spts4,
+                                                               uint2 *__restrict__ row_bounds /* [ny*nz]: begin, end */,
+                                                               uint2 *__restrict__ tiles, uint32_t tiles_cap)
 {
-    const uint32_t n = *n_ptr;
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
-        const uint32_t i = perm[s];
-        float4 p = crop4[i];
-        p.w = __uint_as_float(i);  // cropped index rides in the pad lane
-        spts4[s] = p;
-        // first / one-past-last sorted position of every occupied x-row (only occupied rows are ever read)
-        const uint32_t row = skeys[s] / nx;
-        if (s == 0 || skeys[s - 1] / nx != row) row_bounds[row].x = s;
-        if (s + 1 == n || skeys[s + 1] / nx != row) row_bounds[row].y = s + 1;
-    }
-}
-
-// ---- tiles: <=64 consecutive sorted points of one x-row spanning <= span+1 cells ----
-// Tiles are cut at every 64th point counted from the start of the x-row (so dense rows give
-// full tiles: ~90 % lane fill) and a 64-chunk that spans more than `span` cell steps (sparse
-// rows) is cut again at aligned (span+1)-cell groups, which bounds the candidate count of a
-// tile: without the bound a sparse row yields tiles 20x the mean that the whole grid waits for.
-__global__ __launch_bounds__(1024) void k_build_tiles(const uint32_t *__restrict__ skeys,
-                                                      DevCounters *__restrict__ ctr, uint32_t nx, uint32_t span,
-                                                      const uint2 *__restrict__ row_bounds,
-                                                      uint2 *__restrict__ tiles, uint32_t tiles_cap)
-{
-    __shared__ uint32_t wtot[1024 / kWave];
-    __shared__ uint32_t block_base;
+    __shared__ uint32_t wtot[kTbThreads / kWave], wstart[kTbThreads / kWave];
+    __shared__ uint32_t block_base, s_start0;
     const uint32_t n = ctr->n_cropped;
-    const uint32_t s = blockIdx.x * 1024u + threadIdx.x;
-    if (blockIdx.x * 1024u >= n) return;  // uniform per block
+    const uint32_t base = (blockIdx.x >> 1) * (uint32_t)kTbSpan;
+    if (base >= n) return;  // uniform per block
+    if (blockIdx.x & 1u) {
+        uint32_t idx[kTbPer];
+        float4 p[kTbPer];
+#pragma unroll
+        for (int j = 0; j < kTbPer; ++j) {
+            const uint32_t s = base + j * kTbThreads + threadIdx.x;
+            idx[j] = s < n ? perm[s] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < kTbPer; ++j) p[j] = crop4[idx[j]];   // (n > 0 here: index 0 is readable)
+#pragma unroll
+        for (int j = 0; j < kTbPer; ++j) {
+            const uint32_t s = base + j * kTbThreads + threadIdx.x;
+            p[j].w = __uint_as_float(idx[j]);  // cropped index rides in the pad lane
+            if (s < n) spts4[s] = p[j];
+        }
+        return;
+    }
     const int w = threadIdx.x / kWave;
-    // a point starts a tile iff it starts a 64-chunk of its x-row, or its chunk is "sparse"
-    // (spans more than `span` cell steps) and it is the first point of an aligned cell group
-    uint32_t cnt = 0, tend = 0;
-    if (s < n) {
-        const uint32_t key = skeys[s];
-        const uint32_t row = key / nx;
-        const uint2 rb = row_bounds[row];  // written by k_gather_sorted
-        const uint32_t cstart = rb.x + ((s - rb.x) / (uint32_t)kTileQ) * (uint32_t)kTileQ;
-        const uint32_t cend = (cstart + kTileQ < rb.y) ? cstart + kTileQ : rb.y;
-        const bool sparse = skeys[cend - 1] - skeys[cstart] > span;  // same row: key difference = cell steps
-        const uint32_t group = span + 1u;
-        const uint32_t my_group = (key - row * nx) / group;
-        if (s == cstart) cnt = 1;
-        else if (sparse && my_group != (skeys[s - 1] - row * nx) / group) cnt = 1;
-        if (cnt) {
-            // the tile ends with its 64-chunk or, in a sparse chunk, where the next cell group begins
-            // (keys ascend inside a row: a short binary search, on the rare sparse chunks only)
-            tend = cend;
-            if (sparse) {
-                uint32_t lo = s + 1, hi = cend;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if ((skeys[mid] - row * nx) / group == my_group) lo = mid + 1; else hi = mid;
-                }
-                tend = lo;
-            }
+    const uint32_t s0 = base + threadIdx.x * (uint32_t)kTbPer;   // this thread's first position
+    // keys of the thread's positions and of the two around them (the buffers hold whole 16 B groups: capacity is
+    // allocated in multiples of 4 and the first position of a thread is a multiple of 4)
+    uint32_t key[kTbPer + 2];
+    {
+        const uint4 k4 = s0 < n ? *reinterpret_cast<const uint4 *>(skeys + s0) : make_uint4(0u, 0u, 0u, 0u);
+        key[1] = k4.x; key[2] = k4.y; key[3] = k4.z; key[4] = k4.w;
+        key[0] = (s0 > 0 && s0 < n) ? skeys[s0 - 1] : 0u;
+        key[kTbPer + 1] = s0 + kTbPer < n ? skeys[s0 + kTbPer] : 0u;
+    }
+    uint32_t row[kTbPer];
+    bool starts[kTbPer];
+    uint32_t m = 0;  // nearest row start at or before the thread's last position, +1; 0 = none in this thread
+#pragma unroll
+    for (int j = 0; j < kTbPer; ++j) {
+        const uint32_t s = s0 + j;
+        row[j] = key[j + 1] / nx;
+        starts[j] = false;
+        if (s < n) {
+            starts[j] = s == 0 || key[j] / nx != row[j];
+            if (starts[j]) { row_bounds[row[j]].x = s; m = s + 1u; }
+            if (s + 1 == n || key[j + 2] / nx != row[j]) row_bounds[row[j]].y = s + 1;
         }
     }
+    // ---- start of the row that runs into this block
+    if (threadIdx.x == 0) s_start0 = starts[0] ? base : 0xFFFFFFFFu;
+    __syncthreads();
+    {
+        const uint32_t row0 = skeys[base] / nx;
+        for (uint32_t back = 0; s_start0 == 0xFFFFFFFFu; back += (uint32_t)kTbSpan) {  // block-uniform
+            // positions base-back-4(tid+1) .. +3: the row start is the one position of row0 whose predecessor is not
+            const uint32_t off = back + (threadIdx.x + 1u) * (uint32_t)kTbPer;
+            uint32_t hit = 0xFFFFFFFFu;
+            if (off <= base) {   // (base and off are multiples of 4: the group lies inside [0, base))
+                const uint32_t t0 = base - off;
+                const uint4 k4 = *reinterpret_cast<const uint4 *>(skeys + t0);
+                const uint32_t kk[5] = {t0 ? skeys[t0 - 1] : 0u, k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+                for (int j = 0; j < kTbPer; ++j)
+                    if (kk[j + 1] / nx == row0 && (t0 + j == 0 || kk[j] / nx != row0)) hit = t0 + j;
+            }
+            __syncthreads();            // everyone has read s_start0 for the loop test
+            if (hit != 0xFFFFFFFFu) s_start0 = hit;   // at most one thread over the whole walk
+            __syncthreads();
+        }
+    }
+    // ---- exclusive running maximum of m over the threads before this one
+    uint32_t mi = m;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t t = __shfl_up(mi, o, kWave);
+        if (lane_id() >= o) mi = t > mi ? t : mi;
+    }
+    if (lane_id() == kWave - 1) wstart[w] = mi;
+    uint32_t before = __shfl_up(mi, 1, kWave);
+    if (lane_id() == 0) before = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kTbThreads / kWave; ++k)
+        if (k < w) before = wstart[k] > before ? wstart[k] : before;
+    uint32_t row_start = before ? before - 1u : s_start0;
+    // a point starts a tile iff it starts a 64-chunk of its x-row, or its chunk is "sparse"
+    // (spans more than `span` cell steps) and it is the first point of an aligned cell group
+    uint32_t cnt[kTbPer], tend[kTbPer], total_t = 0;
+    const uint32_t group = span + 1u;
+#pragma unroll
+    for (int j = 0; j < kTbPer; ++j) {
+        const uint32_t s = s0 + j;
+        cnt[j] = 0; tend[j] = 0;
+        if (s < n) {
+            if (starts[j]) row_start = s;
+            const uint32_t r = row[j], kj = key[j + 1];
+            const uint32_t cstart = row_start + ((s - row_start) / (uint32_t)kTileQ) * (uint32_t)kTileQ;
+            const uint32_t my_group = (kj - r * nx) / group;
+            // a tile can only start at the chunk start or where the cell group changes: everything else is skipped
+            // before any further load
+            const bool at_cstart = s == cstart;
+            const bool group_edge = !at_cstart && my_group != (key[j] - r * nx) / group;
+            if (at_cstart || group_edge) {
+                // the chunk ends 64 points on or with the row (keys ascend: a short binary search in the row's last chunk)
+                uint32_t cend = cstart + kTileQ;
+                if (cend > n || skeys[cend - 1] / nx != r) {
+                    uint32_t lo = s + 1, hi = cend < n ? cend : n;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (skeys[mid] / nx == r) lo = mid + 1; else hi = mid;
+                    }
+                    cend = lo;
+                }
+                const bool sparse = skeys[cend - 1] - skeys[cstart] > span;  // same row: key difference = cell steps
+                if (at_cstart || sparse) {
+                    cnt[j] = 1;
+                    // the tile ends with its 64-chunk or, in a sparse chunk, where the next cell group begins
+                    tend[j] = cend;
+                    if (sparse) {
+                        uint32_t lo = s + 1, hi = cend;
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if ((skeys[mid] - r * nx) / group == my_group) lo = mid + 1; else hi = mid;
+                        }
+                        tend[j] = lo;
+                    }
+                }
+            }
+        }
+        total_t += cnt[j];
+    }
     // block-wide exclusive prefix of the flags, ONE atomic per block for the base
-    const uint32_t inc = wave_inclusive_scan(cnt);
+    const uint32_t inc = wave_inclusive_scan(total_t);
     if (lane_id() == kWave - 1) wtot[w] = inc;
     __syncthreads();
     uint32_t woff = 0, total = 0;
 #pragma unroll
-    for (int k = 0; k < 1024 / kWave; ++k) {
+    for (int k = 0; k < kTbThreads / kWave; ++k) {
         const uint32_t c = wtot[k];
         if (k < w) woff += c;
         total += c;
     }
     if (threadIdx.x == 0) block_base = total ? atomicAdd(&ctr->n_tiles, total) : 0u;
     __syncthreads();
-    const uint32_t t_out = block_base + woff + inc - cnt;
-    if (cnt && t_out < tiles_cap) tiles[t_out] = make_uint2(s, tend - s);  // first query, number of queries
+    uint32_t t_out = block_base + woff + inc - total_t;
+#pragma unroll
+    for (int j = 0; j < kTbPer; ++j) {
+        if (cnt[j]) {
+            if (t_out < tiles_cap) tiles[t_out] = make_uint2(s0 + j, tend[j] - (s0 + j));  // first query, number of queries
+            ++t_out;
+        }
+    }
 }
 
 // ---- smallest eigenpair of a symmetric PSD 3x3, fp64 ----------------------------
@@ -1327,14 +1424,11 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     uint32_t *skeys = where ? sl.keys_b : sl.keys_a;
     uint32_t *perm = where ? sl.vals_b : sl.vals_a;
     sl.skeys = skeys;
-    const uint32_t gb = (n_cap + 255) / 256 < 2048 ? (n_cap + 255) / 256 : 2048;
     // rows the frame leaves unoccupied must read as empty ranges in k_normals' window searches
     if (!scratch_cleared) hipMemsetAsync(sl.row_bounds, 0, sizeof(uint2) * (size_t)g.ny * (size_t)g.nz, s);
-    hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(256), 0, s, (const float4 *)sl.crop4, (const uint32_t *)perm,
-                       (const uint32_t *)skeys, (const uint32_t *)&sl.ctr->n_cropped, (uint32_t)g.nx, sl.spts4,
-                       sl.row_bounds);
-    hipLaunchKernelGGL(k_build_tiles, dim3((n_cap + 1023) / 1024), dim3(1024), 0, s, (const uint32_t *)skeys, sl.ctr, (uint32_t)g.nx,
-                       (uint32_t)(kTileSpan * (g.xreach - 1)), (const uint2 *)sl.row_bounds, sl.tiles, sl.tiles_cap);
+    hipLaunchKernelGGL(k_rows_and_tiles, dim3(2u * ((n_cap + kTbSpan - 1) / kTbSpan)), dim3(kTbThreads), 0, s,
+                       (const float4 *)sl.crop4, (const uint32_t *)perm, (const uint32_t *)skeys, sl.ctr, (uint32_t)g.nx,
+                       (uint32_t)(kTileSpan * (g.xreach - 1)), sl.spts4, sl.row_bounds, sl.tiles, sl.tiles_cap);
     // one wave per tile: four tiles per block
     const uint32_t mt = max_tiles(n_cap, g);
     uint32_t nb = (mt + kNrWaves - 1) / kNrWaves;

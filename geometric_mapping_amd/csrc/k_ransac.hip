@@ -187,6 +187,122 @@ __device__ __forceinline__ bool cyl_inlier(float x, float y, float z, float px, 
     return q > lo2 && q < hi2;
 }
 
+// ---- top-K selection by the last block of a scoring launch -----------------------------------------------------------
+// A scoring kernel's blocks add their inlier counts with integer atomics; the block that finishes last (a done-counter)
+// picks the K best of the M scored candidates for the next stage, so no selection kernel sits between two scoring
+// stages.  Order = count descending, hypothesis index ascending, i.e. descending 64-bit keys
+// (count << 13 | 8191 - index) -- all different.  Only the SET matters downstream (the final winner is taken by count
+// and index, not by position), so nothing is sorted: a bitwise radix select finds the K-th largest key (one block-wide
+// count per key bit, ~27 of them) and the candidates at or above it are written in candidate order.
+// Candidate i has count counts[i] and hypothesis index ids ? ids[i] : i (< kMaxHypotheses = 8192);
+// sel[0..K) = the selected hypothesis indices, counts_out[0..K) = 0 (the next stage's counters).
+struct SelectNext {
+    uint32_t *done;            // zero between launches (the last block resets it)
+    const uint32_t *ids;
+    uint32_t M, K;
+    uint32_t *sel;             // nullptr: no selection folded into this launch
+    int32_t *counts_out;
+};
+inline uint32_t select_lds_bytes(uint32_t) { return 0u; }   // (the keys live in registers)
+constexpr uint32_t kSelectFoldMax = 2048;  // candidates (8 keys per thread of a 256-thread block); above that a k_select_topk launch does it
+static_assert(kMaxHypotheses <= 8192, "select keys keep the hypothesis index in 13 bits");
+
+__device__ __forceinline__ void select_by_last_block(const int32_t *__restrict__ counts, const SelectNext nx,
+                                                     unsigned long long * /* unused */)
+{
+    constexpr int kMaxWaves = 16;
+    __shared__ uint32_t s_last, s_cnt[2][kMaxWaves];
+    __shared__ unsigned long long s_or;
+    // This thread's count atomics must be performed before the block reports in.  They are agent-scope RMWs (done at
+    // the coherence point, acknowledged through vmcnt) and the last block reads the counters behind an agent-scope
+    // acquire, so waiting for the acknowledgements is all that is needed -- a __threadfence() here would also write back
+    // the whole L2 from every wave of the grid (measured: +30 us on a 20 us launch).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = gridDim.x * gridDim.y;
+        const uint32_t t = atomicAdd(nx.done, 1u);
+        s_last = t == total - 1u ? 1u : 0u;
+        if (s_last) atomicExch(nx.done, 0u);
+        s_or = 0ull;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // acquire at agent scope (drops this XCD's stale L2 lines -- one block does this, once): the counters can then be
+    // read with plain loads, all in flight together, instead of one agent-scope atomic load after the other
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // (from here on the block is alone on the chip: everything below is latency, so the keys live in registers --
+    //  kSelKeys per thread, unrolled with block-uniform exits -- and the counting uses ballots + scalar popcounts)
+    constexpr int kSelKeys = kSelectFoldMax / 256;
+    const uint32_t T = blockDim.x, nw = T / kWave;
+    const int w = threadIdx.x / kWave;
+    unsigned long long key[kSelKeys];
+    uint32_t cnt_raw[kSelKeys];
+#pragma unroll
+    for (int q = 0; q < kSelKeys; ++q) {   // all loads in flight together
+        const uint32_t i = (uint32_t)q * T + threadIdx.x;
+        cnt_raw[q] = i < nx.M ? (uint32_t)counts[i] : 0u;
+    }
+    unsigned long long my_or = 0ull;
+#pragma unroll
+    for (int q = 0; q < kSelKeys; ++q) {
+        const uint32_t i = (uint32_t)q * T + threadIdx.x;
+        key[q] = 0ull;
+        if (i < nx.M) {
+            const uint32_t h = nx.ids ? nx.ids[i] : i;
+            key[q] = ((unsigned long long)cnt_raw[q] << 13) | (unsigned long long)(8191u - (h & 8191u));
+        }
+        my_or |= key[q];
+    }
+    if (my_or) atomicOr(&s_or, my_or);
+    __syncthreads();
+    unsigned long long kth = 0ull;  // K >= M: everything is selected
+    if (nx.K < nx.M) {
+        const int hi = 63 - __builtin_clzll(s_or | 1ull);
+        uint32_t need = nx.K;
+        int buf = 0;
+        for (int b = hi; b >= 0; --b, buf ^= 1) {
+            const unsigned long long cand = (kth | (1ull << b)) >> b;
+            uint32_t c = 0;  // wave-uniform
+#pragma unroll
+            for (int q = 0; q < kSelKeys; ++q) {
+                if ((uint32_t)q * T >= nx.M) break;   // block-uniform
+                c += (uint32_t)__popcll(__ballot((uint32_t)q * T + threadIdx.x < nx.M && (key[q] >> b) == cand));
+            }
+            if (lane_id() == 0) s_cnt[buf][w] = c;
+            __syncthreads();
+            uint32_t all = 0;
+            for (uint32_t k = 0; k < nw; ++k) all += s_cnt[buf][k];
+            // `all` keys share the prefix found so far and have bit b set: the K-th largest is among them iff all >= need
+            if (all >= need) kth |= 1ull << b; else need -= all;
+        }
+    }
+    // keys >= kth, in candidate order
+    uint32_t running = 0;
+    int buf = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kSelKeys; ++q) {
+        if ((uint32_t)q * T >= nx.M) break;   // block-uniform
+        const uint32_t i = (uint32_t)q * T + threadIdx.x;
+        const bool take = i < nx.M && key[q] >= kth;
+        const uint64_t m = __ballot(take);
+        if (lane_id() == 0) s_cnt[buf][w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (uint32_t k = 0; k < nw; ++k) {
+            const uint32_t c = s_cnt[buf][k];
+            if ((int)k < w) woff += c;
+            tot += c;
+        }
+        const uint32_t dst = running + woff + (uint32_t)__popcll(m & lanemask_lt());
+        if (take && dst < nx.K) nx.sel[dst] = 8191u - (uint32_t)(key[q] & 8191ull);
+        running += tot;
+        buf ^= 1;
+    }
+    for (uint32_t r = threadIdx.x; r < nx.K; r += T) nx.counts_out[r] = 0;
+}
+
 // MODEL 0: plane, 1: cylinder.  Block (x, y) scores hypotheses [y*256, y*256+256) against points
 // [x*kScTile, +kScTile).  lane <-> hypothesis: each lane keeps ITS hypothesis in registers and a
 // private inlier counter; the block's points are staged once in LDS (coalesced 16 B loads, masked
@@ -202,8 +318,9 @@ __global__ __launch_bounds__(kScThreads) void k_score(const float4 *__restrict__
                                                       const uint32_t *__restrict__ n_ptr, uint32_t n_host,
                                                       const float *__restrict__ hyp8,
                                                       const float2 *__restrict__ band, uint32_t H, float tau,
-                                                      uint32_t stride, int32_t *__restrict__ counts)
+                                                      uint32_t stride, int32_t *__restrict__ counts, SelectNext nx)
 {
+    extern __shared__ unsigned long long sel_keys[];
     // points in LDS as groups of four, SoA inside a group: x0..x3 | y0..y3 | z0..z3, so three
     // broadcast ds_read_b128 deliver four points
     __shared__ float4 lp[kScTile / 4][3];
@@ -211,7 +328,7 @@ __global__ __launch_bounds__(kScThreads) void k_score(const float4 *__restrict__
     const uint32_t n_full = n_ptr ? *n_ptr : n_host;
     const uint32_t n = (n_full + stride - 1) / stride;
     const uint32_t base = blockIdx.x * kScTile;
-    if (base >= n) return;  // uniform per block
+    if (base < n) {  // uniform per block
     const uint32_t m = (n - base < (uint32_t)kScTile) ? n - base : (uint32_t)kScTile;
     const uint32_t groups = (m + 3u) >> 2;
 #pragma unroll
@@ -265,6 +382,8 @@ __global__ __launch_bounds__(kScThreads) void k_score(const float4 *__restrict__
         const uint32_t h = blockIdx.y * kScHC + k * kScThreads + threadIdx.x;
         if (h < H && c[k] > 0.f) atomicAdd(&counts[h], (int32_t)c[k]);
     }
+    }
+    if (nx.sel) select_by_last_block(counts, nx, sel_keys);
 }
 
 // arg-max over the hypothesis counts (largest count, lowest index on ties)
@@ -300,7 +419,8 @@ __global__ __launch_bounds__(1024) void k_best_hypothesis(const int32_t *__restr
 constexpr int kPre1Stride = 32, kPre1Keep = 256;
 constexpr int kPre2Stride = 8, kPre2Keep = 32;
 // scratch layout (uint32 words): selA[256] cntA[256] selB[32] cntB[32]
-constexpr int kPreSelA = 0, kPreCntA = 256, kPreSelB = 512, kPreCntB = 544;  // 576 words in all (gm_ensure_ext allocates 1024)
+constexpr int kPreSelA = 0, kPreCntA = 256, kPreSelB = 512, kPreCntB = 544;  // 576 words, then
+constexpr int kPreDone = 576;  // the done-counter of select_by_last_block: zero between launches (gm_ensure_ext allocates 1024 zeroed words)
 
 // Top-K of M scored candidates.  Candidate i has count counts[i] and hypothesis index ids ? ids[i] : i; order =
 // count descending, hypothesis index ascending.  sel[rank] = hypothesis index; block 0 also clears counts_out[0..K).
@@ -338,8 +458,9 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
                                                    uint32_t want, const uint32_t *__restrict__ n_ptr, uint32_t n_host,
                                                    const float *__restrict__ hyp8, const float2 *__restrict__ band,
                                                    const uint32_t *__restrict__ sel, uint32_t K, float tau,
-                                                   uint32_t stride, int32_t *__restrict__ counts_k)
+                                                   uint32_t stride, int32_t *__restrict__ counts_k, SelectNext nx)
 {
+    extern __shared__ unsigned long long sel_keys[];
     constexpr int PTS = 256;  // per wave
     __shared__ float4 lp[4][PTS / 4][3];
     __shared__ float red[4][64];
@@ -353,7 +474,7 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
     const uint32_t base = (blockIdx.x * 4u + wave) * PTS;
     const uint32_t m = base >= n ? 0u : ((n - base < (uint32_t)PTS) ? n - base : (uint32_t)PTS);
     const uint32_t groups = (m + 3u) >> 2;
-    if (blockIdx.x * 4u * PTS >= n) return;  // uniform per block
+    if (blockIdx.x * 4u * PTS < n) {  // uniform per block
 #pragma unroll
     for (int p = 0; p < PTS / 64; ++p) {
         const uint32_t j = p * 64 + lane;
@@ -396,6 +517,8 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
         if (split) t += red[0][lane + 32] + red[1][lane + 32] + red[2][lane + 32] + red[3][lane + 32];
         if (t > 0.f) atomicAdd(&counts_k[slot], (int32_t)t);
     }
+    }
+    if (nx.sel) select_by_last_block(counts_k, nx, sel_keys);
 }
 
 
@@ -550,14 +673,14 @@ __global__ __launch_bounds__(256) void k_ext_finalize(const float *__restrict__ 
                                const float *__restrict__ hyp_cyl, const uint32_t *__restrict__ best_cyl,
                                double *__restrict__ mom_plane, double *__restrict__ mom_cyl,
                                FrameExt *__restrict__ ext, const double *__restrict__ partial, uint32_t mom_rows,
-                               const double *__restrict__ scatter_partials, uint32_t scatter_rows,
+                               const double *__restrict__ scatter_partials, uint32_t scatter_rows, uint32_t row_tile,
                                const DevCounters *__restrict__ ctr, const VoxelParams *__restrict__ voxp,
                                FrameOut *__restrict__ frame_out)
 {
     // the frame's own closing step rides along (frame pipeline only): one launch instead of two single-block ones
     if (frame_out) {
         __shared__ double fred[256 * 6];
-        frame_finalize_block(scatter_partials, scatter_rows, ctr, voxp, frame_out, fred);
+        frame_finalize_block(scatter_partials, scatter_rows, ctr, voxp, frame_out, fred, row_tile);
         __syncthreads();
     }
     if (mom_rows) {   // fixed-order reduction of the label passes' partial rows: partial = [model][kScatterBlocks][16]
@@ -649,11 +772,11 @@ void launch_score(int model, const float4 *pts, const uint8_t *labels, uint32_t 
     hipMemsetAsync(counts, 0, sizeof(int32_t) * H, s);
     if (model == 0) {
         hipLaunchKernelGGL(k_score<0>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
-                           (const float2 *)band, H, (float)tau, 1u, counts);
+                           (const float2 *)band, H, (float)tau, 1u, counts, SelectNext{});
     } else {
         hipLaunchKernelGGL(k_cyl_bands, dim3((H + 255) / 256), dim3(256), 0, s, hyp8, H, tau, band);
         hipLaunchKernelGGL(k_score<1>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
-                           (const float2 *)band, H, (float)tau, 1u, counts);
+                           (const float2 *)band, H, (float)tau, 1u, counts, SelectNext{});
     }
     hipLaunchKernelGGL(k_best_hypothesis, dim3(1), dim3(1024), 0, s, (const int32_t *)counts, H, best);
 }
@@ -662,25 +785,27 @@ void launch_score(int model, const float4 *pts, const uint8_t *labels, uint32_t 
 // kPreScratchWords words.  Returns false when H was small enough for the exhaustive scorer (the winner is then in
 // `best`); otherwise the winner is still to be taken from (*sel_out, *cnt_out, *k_out) -- the label kernel does that.
 // prepared: the hypothesis kernel already cleared `counts` and wrote the cylinder bands.
+// next.sel != nullptr: the launch's last block also selects the next stage's candidates (select_by_last_block)
 template <int MODEL>
 static void score_stage_all(const float4 *pts, const uint8_t *labels, uint32_t want, const uint32_t *n_ptr, uint32_t n_cap,
                             const float *hyp8, const float2 *band, uint32_t H, double tau, uint32_t stride,
-                            int32_t *counts, hipStream_t s)
+                            int32_t *counts, const SelectNext &next, hipStream_t s)
 {
     const uint32_t n_sub = (n_cap + stride - 1) / stride;
     const uint32_t nb = score_blocks(n_sub) ? score_blocks(n_sub) : 1;
-    hipLaunchKernelGGL(k_score<MODEL>, dim3(nb, (H + kScHC - 1) / kScHC), dim3(kScThreads), 0, s, pts, labels, want, n_ptr,
-                       n_cap, hyp8, band, H, (float)tau, stride, counts);
+    hipLaunchKernelGGL(k_score<MODEL>, dim3(nb, (H + kScHC - 1) / kScHC), dim3(kScThreads),
+                       next.sel ? select_lds_bytes(next.M) : 0u, s, pts, labels, want, n_ptr, n_cap, hyp8, band, H,
+                       (float)tau, stride, counts, next);
 }
 template <int MODEL>
 static void score_stage_sel(const float4 *pts, const uint8_t *labels, uint32_t want, const uint32_t *n_ptr, uint32_t n_cap,
                             const float *hyp8, const float2 *band, const uint32_t *sel, uint32_t K, double tau,
-                            uint32_t stride, int32_t *counts_k, hipStream_t s)
+                            uint32_t stride, int32_t *counts_k, const SelectNext &next, hipStream_t s)
 {
     const uint32_t n_sub = (n_cap + stride - 1) / stride;
     const uint32_t nb = (n_sub + 1023) / 1024 ? (n_sub + 1023) / 1024 : 1;
-    hipLaunchKernelGGL(k_score_sel<MODEL>, dim3(nb, (K + 63) / 64), dim3(256), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
-                       band, sel, K, (float)tau, stride, counts_k);
+    hipLaunchKernelGGL(k_score_sel<MODEL>, dim3(nb, (K + 63) / 64), dim3(256), next.sel ? select_lds_bytes(next.M) : 0u, s,
+                       pts, labels, want, n_ptr, n_cap, hyp8, band, sel, K, (float)tau, stride, counts_k, next);
 }
 static void select_topk(const int32_t *counts, const uint32_t *ids, uint32_t M, uint32_t K, uint32_t *sel,
                         int32_t *counts_out, hipStream_t s)
@@ -706,21 +831,27 @@ bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels
     }
     const float2 *cb = band;
     const uint32_t K2 = kPre2Keep;
+    uint32_t *done = scratch + kPreDone;
+    const SelectNext none{};
+    // (a selection over more than kSelectFoldMax candidates keeps its own launch: the LDS sort would not fit)
     if (H > (uint32_t)kPre1Keep) {
         const uint32_t K1 = kPre1Keep;
-        if (model == 0) score_stage_all<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre1Stride, counts, s);
-        else score_stage_all<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre1Stride, counts, s);
-        select_topk(counts, nullptr, H, K1, selA, cntA, s);
-        if (model == 0) score_stage_sel<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selA, K1, tau, kPre2Stride, cntA, s);
-        else score_stage_sel<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selA, K1, tau, kPre2Stride, cntA, s);
-        select_topk(cntA, selA, K1, K2, selB, cntB, s);
+        static const char *own = getenv("GM_RANSAC_SELECT");   // "kernel": selections keep their own launches (A/B timing)
+        const bool fold = H <= kSelectFoldMax && !(own && own[0] == 'k');
+        const SelectNext n1{done, nullptr, H, K1, selA, cntA}, n2{done, selA, K1, K2, selB, cntB};
+        if (model == 0) score_stage_all<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre1Stride, counts, fold ? n1 : none, s);
+        else score_stage_all<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre1Stride, counts, fold ? n1 : none, s);
+        if (!fold) select_topk(counts, nullptr, H, K1, selA, cntA, s);
+        if (model == 0) score_stage_sel<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selA, K1, tau, kPre2Stride, cntA, fold ? n2 : none, s);
+        else score_stage_sel<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selA, K1, tau, kPre2Stride, cntA, fold ? n2 : none, s);
+        if (!fold) select_topk(cntA, selA, K1, K2, selB, cntB, s);
     } else {
-        if (model == 0) score_stage_all<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre2Stride, counts, s);
-        else score_stage_all<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre2Stride, counts, s);
-        select_topk(counts, nullptr, H, K2, selB, cntB, s);
+        const SelectNext n2{done, nullptr, H, K2, selB, cntB};
+        if (model == 0) score_stage_all<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre2Stride, counts, n2, s);
+        else score_stage_all<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre2Stride, counts, n2, s);
     }
-    if (model == 0) score_stage_sel<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selB, K2, tau, 1u, cntB, s);
-    else score_stage_sel<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selB, K2, tau, 1u, cntB, s);
+    if (model == 0) score_stage_sel<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selB, K2, tau, 1u, cntB, none, s);
+    else score_stage_sel<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selB, K2, tau, 1u, cntB, none, s);
     *sel_out = selB; *cnt_out = cntB; *k_out = K2;
     return true;
 }
@@ -761,10 +892,11 @@ void launch_segment_moments(const float4 *pts, const float4 *nrm, const uint8_t 
 void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, const float *hyp_cyl,
                          const uint32_t *best_cyl, double *mom_plane, double *mom_cyl, FrameExt *ext,
                          const double *partial32, uint32_t mom_rows, hipStream_t s, const double *scatter_partials,
-                         uint32_t scatter_rows, const DevCounters *ctr, const VoxelParams *voxp, FrameOut *frame_out)
+                         uint32_t scatter_rows, uint32_t row_tile, const DevCounters *ctr, const VoxelParams *voxp,
+                         FrameOut *frame_out)
 {
     hipLaunchKernelGGL(k_ext_finalize, dim3(1), dim3(256), 0, s, hyp_plane, best_plane, hyp_cyl, best_cyl, mom_plane,
-                       mom_cyl, ext, partial32, mom_rows, scatter_partials, scatter_rows, ctr, voxp, frame_out);
+                       mom_cyl, ext, partial32, mom_rows, scatter_partials, scatter_rows, row_tile, ctr, voxp, frame_out);
 }
 
 }  // namespace gm

@@ -66,6 +66,7 @@ struct HeadPred {
     __device__ __forceinline__ bool operator()(uint32_t s) const { return s == 0 || skeys[s] != skeys[s - 1]; }
 };
 struct HeadEmit {
+    static constexpr bool kHasFinish = false;
     uint32_t *__restrict__ seg_start;
     __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst) const { seg_start[dst] = src; }
 };
@@ -100,6 +101,7 @@ struct DensePred {
     __device__ __forceinline__ bool operator()(uint32_t i) const { return table[i].cnt != 0; }
 };
 struct DenseEmit {
+    static constexpr bool kHasFinish = false;
     const VoxCell *__restrict__ table;
     float4 *__restrict__ vox4;
     double lo, inv_scale;
@@ -115,13 +117,10 @@ struct DenseEmit {
 void launch_voxel_dense_finalize(const VoxDense &vd, Slot &sl, hipStream_t s)
 {
     const uint32_t cells = (uint32_t)vd.dim * vd.dim * vd.dim;
-    const uint32_t nb = compact_blocks(cells);
     DensePred pred{sl.vox_table};
     DenseEmit emit{sl.vox_table, sl.vox4, (double)vd.lo, vd.inv_scale};
-    hipLaunchKernelGGL(k_compact_count<DensePred>, dim3(nb), dim3(kCpThreads), 0, s, pred, (const uint32_t *)nullptr,
-                       cells, sl.blk);
-    hipLaunchKernelGGL((k_compact_scatter<DensePred, DenseEmit>), dim3(nb), dim3(kCpThreads), 0, s, pred, emit,
-                       (const uint32_t *)nullptr, cells, (const uint32_t *)sl.blk, nb, &sl.ctr->n_voxels, (uint32_t *)nullptr);
+    hipLaunchKernelGGL((k_compact<DensePred, DenseEmit>), dim3(compact_grid(cells)), dim3(kCpThreads), 0, s, pred, emit,
+                       (const uint32_t *)nullptr, cells, next_scan(sl), &sl.ctr->n_voxels, (uint32_t *)nullptr);
 }
 
 void launch_voxel_grid(Slot &sl, uint32_t n_cap, float leaf, int key_bits, hipStream_t s)
@@ -136,13 +135,10 @@ void launch_voxel_grid(Slot &sl, uint32_t n_cap, float leaf, int key_bits, hipSt
                                         sl.sort, false, s);
     const uint32_t *skeys = where ? sl.keys_b : sl.keys_a;
     const uint32_t *perm = where ? sl.vals_b : sl.vals_a;
-    const uint32_t nb = compact_blocks(n_cap);
     HeadPred pred{skeys};
     HeadEmit emit{sl.seg_start};
-    hipLaunchKernelGGL(k_compact_count<HeadPred>, dim3(nb), dim3(kCpThreads), 0, s, pred,
-                       (const uint32_t *)&sl.ctr->vox_n, 0u, sl.blk);
-    hipLaunchKernelGGL((k_compact_scatter<HeadPred, HeadEmit>), dim3(nb), dim3(kCpThreads), 0, s, pred, emit,
-                       (const uint32_t *)&sl.ctr->vox_n, 0u, (const uint32_t *)sl.blk, nb, &sl.ctr->n_voxels, (uint32_t *)nullptr);
+    hipLaunchKernelGGL((k_compact<HeadPred, HeadEmit>), dim3(compact_grid(n_cap)), dim3(kCpThreads), 0, s, pred, emit,
+                       (const uint32_t *)&sl.ctr->vox_n, 0u, next_scan(sl), &sl.ctr->n_voxels, (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_voxel_centroids, dim3(gb), dim3(256), 0, s, (const float4 *)sl.valid4, perm,
                        (const uint32_t *)sl.seg_start, (const DevCounters *)sl.ctr, sl.vox4);
 }
