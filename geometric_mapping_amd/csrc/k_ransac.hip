@@ -210,8 +210,7 @@ static_assert(kMaxHypotheses <= 8192, "select keys keep the hypothesis index in 
 __device__ __forceinline__ void select_by_last_block(const int32_t *__restrict__ counts, const SelectNext nx,
                                                      unsigned long long * /* unused */)
 {
-    constexpr int kMaxWaves = 16;
-    __shared__ uint32_t s_last, s_cnt[2][kMaxWaves];
+    __shared__ uint32_t s_last;
     __shared__ unsigned long long s_or;
     // This thread's count atomics must be performed before the block reports in.  They are agent-scope RMWs (done at
     // the coherence point, acknowledged through vmcnt) and the last block reads the counters behind an agent-scope
@@ -231,9 +230,12 @@ __device__ __forceinline__ void select_by_last_block(const int32_t *__restrict__
     // acquire at agent scope (drops this XCD's stale L2 lines -- one block does this, once): the counters can then be
     // read with plain loads, all in flight together, instead of one agent-scope atomic load after the other
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    // (from here on the block is alone on the chip: everything below is latency, so the keys live in registers --
-    //  kSelKeys per thread, unrolled with block-uniform exits -- and the counting uses ballots + scalar popcounts)
-    constexpr int kSelKeys = kSelectFoldMax / 256;
+    // From here on the block is alone on the chip and every dependent step (an LDS round trip, a barrier) costs its
+    // full latency -- measured ~0.5 us per barrier-separated step -- so the search takes 4 key bits per step (a 16-bin
+    // histogram in LDS, one barrier), the keys stay in registers, and the output ranks need one barrier in all.
+    constexpr int kSelKeys = kSelectFoldMax / 256;   // keys per thread (blocks of >= 256 threads)
+    constexpr int kMaxWaves = 16;
+    __shared__ uint32_t s_hist[16][16], s_cnt[kSelKeys][kMaxWaves];
     const uint32_t T = blockDim.x, nw = T / kWave;
     const int w = threadIdx.x / kWave;
     unsigned long long key[kSelKeys];
@@ -255,52 +257,62 @@ __device__ __forceinline__ void select_by_last_block(const int32_t *__restrict__
         my_or |= key[q];
     }
     if (my_or) atomicOr(&s_or, my_or);
+    for (uint32_t t = threadIdx.x; t < 256u; t += T) s_hist[t >> 4][t & 15u] = 0u;
+    for (uint32_t r = threadIdx.x; r < nx.K; r += T) nx.counts_out[r] = 0;
     __syncthreads();
     unsigned long long kth = 0ull;  // K >= M: everything is selected
     if (nx.K < nx.M) {
-        const int hi = 63 - __builtin_clzll(s_or | 1ull);
         uint32_t need = nx.K;
-        int buf = 0;
-        for (int b = hi; b >= 0; --b, buf ^= 1) {
-            const unsigned long long cand = (kth | (1ull << b)) >> b;
-            uint32_t c = 0;  // wave-uniform
+        for (int d = (63 - __builtin_clzll(s_or | 1ull)) >> 2; d >= 0; --d) {
+            const int shift = 4 * d;
 #pragma unroll
             for (int q = 0; q < kSelKeys; ++q) {
                 if ((uint32_t)q * T >= nx.M) break;   // block-uniform
-                c += (uint32_t)__popcll(__ballot((uint32_t)q * T + threadIdx.x < nx.M && (key[q] >> b) == cand));
+                const bool in = (uint32_t)q * T + threadIdx.x < nx.M;
+                // keys that share the digits found so far
+                const bool match = shift + 4 >= 64 || (key[q] >> (shift + 4)) == (kth >> (shift + 4));
+                if (in && match) atomicAdd(&s_hist[d][(uint32_t)(key[q] >> shift) & 15u], 1u);
             }
-            if (lane_id() == 0) s_cnt[buf][w] = c;
             __syncthreads();
-            uint32_t all = 0;
-            for (uint32_t k = 0; k < nw; ++k) all += s_cnt[buf][k];
-            // `all` keys share the prefix found so far and have bit b set: the K-th largest is among them iff all >= need
-            if (all >= need) kth |= 1ull << b; else need -= all;
+            uint32_t bins[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) bins[v] = s_hist[d][v];
+            // the K-th largest has the highest digit v for which (#keys with a digit above v) < need
+            uint32_t above = 0, digit = 0, sub = 0;
+            bool found = false;
+#pragma unroll
+            for (int v = 15; v >= 0; --v) {
+                if (!found && above + bins[v] >= need) { digit = (uint32_t)v; sub = above; found = true; }
+                above += bins[v];
+            }
+            need -= sub;
+            kth |= (unsigned long long)digit << shift;
         }
     }
-    // keys >= kth, in candidate order
-    uint32_t running = 0;
-    int buf = 0;
+    // keys >= kth, in candidate order: candidate q*T + t comes after every candidate of the chunks before q
+#pragma unroll
+    for (int q = 0; q < kSelKeys; ++q) {
+        const bool take = (uint32_t)q * T + threadIdx.x < nx.M && key[q] >= kth;
+        const uint64_t m = __ballot(take);
+        if (lane_id() == 0) s_cnt[q][w] = (uint32_t)__popcll(m);
+    }
     __syncthreads();
+    uint32_t running = 0;
 #pragma unroll
     for (int q = 0; q < kSelKeys; ++q) {
         if ((uint32_t)q * T >= nx.M) break;   // block-uniform
-        const uint32_t i = (uint32_t)q * T + threadIdx.x;
-        const bool take = i < nx.M && key[q] >= kth;
+        const bool take = (uint32_t)q * T + threadIdx.x < nx.M && key[q] >= kth;
         const uint64_t m = __ballot(take);
-        if (lane_id() == 0) s_cnt[buf][w] = (uint32_t)__popcll(m);
-        __syncthreads();
         uint32_t woff = 0, tot = 0;
         for (uint32_t k = 0; k < nw; ++k) {
-            const uint32_t c = s_cnt[buf][k];
+            const uint32_t c = s_cnt[q][k];
             if ((int)k < w) woff += c;
             tot += c;
         }
         const uint32_t dst = running + woff + (uint32_t)__popcll(m & lanemask_lt());
         if (take && dst < nx.K) nx.sel[dst] = 8191u - (uint32_t)(key[q] & 8191ull);
         running += tot;
-        buf ^= 1;
     }
-    for (uint32_t r = threadIdx.x; r < nx.K; r += T) nx.counts_out[r] = 0;
 }
 
 // MODEL 0: plane, 1: cylinder.  Block (x, y) scores hypotheses [y*256, y*256+256) against points
@@ -677,11 +689,12 @@ __global__ __launch_bounds__(256) void k_ext_finalize(const float *__restrict__ 
                                const DevCounters *__restrict__ ctr, const VoxelParams *__restrict__ voxp,
                                FrameOut *__restrict__ frame_out)
 {
-    // the frame's own closing step rides along (frame pipeline only): one launch instead of two single-block ones
-    if (frame_out) {
+    // the frame's own closing step rides along (frame pipeline only) as a second block: one launch instead of two
+    // single-block ones, and the two latency chains (reduce + 3x3 solves each) run side by side
+    if (blockIdx.x == 1) {
         __shared__ double fred[256 * 6];
-        frame_finalize_block(scatter_partials, scatter_rows, ctr, voxp, frame_out, fred, row_tile);
-        __syncthreads();
+        if (frame_out) frame_finalize_block(scatter_partials, scatter_rows, ctr, voxp, frame_out, fred, row_tile);
+        return;
     }
     if (mom_rows) {   // fixed-order reduction of the label passes' partial rows: partial = [model][kScatterBlocks][16]
         __shared__ double red[8][32];
@@ -707,7 +720,7 @@ __global__ __launch_bounds__(256) void k_ext_finalize(const float *__restrict__ 
         __threadfence_block();
         __syncthreads();
     }
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
     FrameExt e;
     for (int k = 0; k < 4; ++k) { e.plane[k] = __builtin_nanf(""); e.plane_refit[k] = __builtin_nan(""); }
     for (int k = 0; k < 7; ++k) e.cylinder[k] = __builtin_nanf("");
@@ -895,7 +908,7 @@ void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, con
                          uint32_t scatter_rows, uint32_t row_tile, const DevCounters *ctr, const VoxelParams *voxp,
                          FrameOut *frame_out)
 {
-    hipLaunchKernelGGL(k_ext_finalize, dim3(1), dim3(256), 0, s, hyp_plane, best_plane, hyp_cyl, best_cyl, mom_plane,
+    hipLaunchKernelGGL(k_ext_finalize, dim3(frame_out ? 2 : 1), dim3(256), 0, s, hyp_plane, best_plane, hyp_cyl, best_cyl, mom_plane,
                        mom_cyl, ext, partial32, mom_rows, scatter_partials, scatter_rows, row_tile, ctr, voxp, frame_out);
 }
 

@@ -134,12 +134,12 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__res
         const int col = threadIdx.x % BINS, rg = threadIdx.x / BINS;
         uint32_t acc = 0;
         uint32_t b = (uint32_t)rg;
-        for (; b + 7u * RG < blockIdx.x; b += 8u * RG) {
-            uint32_t r[8];
+        for (; b + 15u * RG < blockIdx.x; b += 16u * RG) {
+            uint32_t r[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) r[u] = hist[(size_t)(b + (uint32_t)u * RG) * BINS + col];
+            for (int u = 0; u < 16; ++u) r[u] = hist[(size_t)(b + (uint32_t)u * RG) * BINS + col];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += r[u];
+            for (int u = 0; u < 16; ++u) acc += r[u];
         }
         for (; b < blockIdx.x; b += RG) acc += hist[(size_t)b * BINS + col];
         colsum[threadIdx.x] = acc;
@@ -164,14 +164,16 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_scatter(const uint32_t *__res
     } else if (threadIdx.x * PER < BINS) {
         const uint32_t *col = hist + threadIdx.x * PER;
         uint32_t b = 0;
-        for (; b + 8 <= blockIdx.x; b += 8) {  // 8 rows in flight per step
-            uint32_t r[8][PER];
+        // (the last block's chain of dependent L2 round trips is the launch's critical path: 32 rows in flight per step)
+        constexpr int kInFlight = 32 / PER;
+        for (; b + kInFlight <= blockIdx.x; b += kInFlight) {
+            uint32_t r[kInFlight][PER];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < kInFlight; ++u)
 #pragma unroll
                 for (int k = 0; k < PER; ++k) r[u][k] = col[(size_t)(b + u) * BINS + k];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < kInFlight; ++u)
 #pragma unroll
                 for (int k = 0; k < PER; ++k) before[k] += r[u][k];
         }
