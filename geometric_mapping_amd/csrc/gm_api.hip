@@ -92,6 +92,10 @@ GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, flo
         g.snap = ldexpf(1.0f, e - 24 < -120 ? -120 : e - 24);
         static const char *bs = getenv("GM_MX_BAND_SCALE");   // experiments only
         g.band = 2.0e-5f * h * h * (bs ? (float)atof(bs) : 1.0f);
+        int be = 0;
+        (void)frexpf(1.0f / g.band, &be);                    // 1/band = m * 2^be, m in [0.5, 1)  =>  2^be >= 1/band
+        g.dscale = ldexpf(1.0f, be > 60 ? 60 : be);
+        g.dband = g.band * g.dscale;
     }
     return g;
 }

@@ -57,6 +57,10 @@ struct GridParams {
     float snap;         // power of two >= one ulp of the largest coordinate of the grid box: tile origins of the
                         // matrix-core kernel are multiples of it, which makes point - origin exact up to the rounding of a
                         // radius-sized number
+    float dscale;       // power of two >= 1 / band: the distance MFMA of k_normals computes T = (r2 - d2) * dscale, so that
+                        // one v_cvt_pk_bf16_f32 with clamp turns two of them into two 0/1 weights (every T in (0, 1) lies
+                        // inside the band and is re-evaluated exactly)
+    float dband;        // band * dscale, in [1, 2)
     float band;         // half-width of the band around r2 inside which the distance MFMA's value does not decide a pair
                         // (5e-5 * cell edge^2: >= 20x the error measured by tools/microbench/mfma_probe.hip for offsets
                         // of the size a tile and its windows span)

@@ -1092,9 +1092,9 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         const float ox = rintf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q.x), mid)) * inv_snap) * g.snap,
                     oy = rintf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q.y), mid)) * inv_snap) * g.snap,
                     oz = rintf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q.z), mid)) * inv_snap) * g.snap;
-        const float big = g.r2_scale;
-        const v2f big2 = {big, big}, r2v = {g.r2, g.r2};
+#ifdef GM_MD_DEBUG
         const float band = g.band;
+#endif
         const int ngroups = qn > (uint32_t)kMxGroupLanes ? 2 : 1;  // (a second group of repeated queries is skipped)
         f32x16 acc[kMxGroups];
 
@@ -1115,8 +1115,13 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             const float vx = gq[gi][0] - ox, vy = gq[gi][1] - oy, vz = gq[gi][2] - oz;
             const float vv = __fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz));
             uint32_t sv[3], sx[3], sy[3], sz[3];
-            md_split3(vv, sv); md_split3(-2.0f * vx, sx); md_split3(-2.0f * vy, sy); md_split3(-2.0f * vz, sz);
-            const uint32_t one = 0x3F80u;
+            // The product is t = r2 - d2 itself: the |u|^2 rows meet -1, the constant row meets r2 - |v|^2 (one more
+            // rounding of a number of size r2: 6e-8 r2, far inside the band), the u rows meet +2v -- so the weights
+            // below need no subtraction.
+            // Everything times dscale (a power of two: exact), see GridParams.
+            const float S = g.dscale;
+            md_split3(__fsub_rn(g.r2, vv) * S, sv); md_split3(2.0f * S * vx, sx); md_split3(2.0f * S * vy, sy); md_split3(2.0f * S * vz, sz);
+            const uint32_t one = __float_as_uint(-S) >> 16;   // bf16(-dscale)
             // k-slots 0..31: 1,1,1 | vv h,m,l | x: h,m,l,h,m,h | y: ... | z: ... | 0 x 8   (16-bit patterns)
             const uint32_t s0[8] = {one, one, one, sv[0], sv[1], sv[2], sx[0], sx[1]};            // slots 0..7
             const uint32_t s1[8] = {sx[2], sx[0], sx[1], sx[0], sy[0], sy[1], sy[2], sy[0]};      // slots 8..15
@@ -1253,14 +1258,16 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                     d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, qb[gi][1], d1, 0, 0, 0);
                     // ---- weights: 1 where d2 < r2.  d1 is within `band` of FLANN's fp32 value (mfma_probe.hip): outside the
                     // band the decision is certain; inside it the pair is re-evaluated exactly as FLANN does
-                    v2f wv[8];
+                    uint32_t pw[8];   // two bf16 weights each: candidates 2k (low half) and 2k + 1 of this lane's 16
                     float amin = 3.0e38f;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const v2f tt = r2v - (v2f){d1[2 * k], d1[2 * k + 1]};
-                        asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(wv[k]) : "v"(tt), "v"(big2));   // clamp01(t * 2^100 / r2)
-                        amin = fminf(fminf(fabsf(tt.x), fabsf(tt.y)), amin);
-                    }
+                    for (int k = 0; k < 8; ++k) amin = fminf(fminf(fabsf(d1[2 * k]), fabsf(d1[2 * k + 1])), amin);
+                    // clamp01 of T = (r2 - d2) * dscale, rounded to bf16: exactly 1 or 0 outside the band.  (The asm takes
+                    // amin as an operand it does not use: that orders it behind the compiler's own reads of d1, for which
+                    // the MFMA -> VALU wait states are inserted; nothing inserts them for an asm statement.)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(pw[k]) : "v"(d1[2 * k]), "v"(d1[2 * k + 1]), "v"(amin));
 #ifdef GM_MD_DEBUG   // diagnostic build: error of the distance MFMA against FLANN's fp32 value, every pair
                     {
                         const float vx = gq[gi][0] - ox, vy = gq[gi][1] - oy, vz = gq[gi][2] - oz;
@@ -1271,11 +1278,12 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                                 const float4 c = spts4[c0 + p + rk];
                                 const float dx = c.x - gq[gi][0], dy = c.y - gq[gi][1], dz = c.z - gq[gi][2];
                                 const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-                                const float err = fabsf(d1[k] - d2) / g.r2;
+                                const float d1k = g.r2 - d1[k] / g.dscale;
+                                const float err = fabsf(d1k - d2) / g.r2;
                                 if (d2 < 4.0f * g.r2) {
                                     atomicMax(&ctr->pad[1], __float_as_uint(err));
                                     if (err > 1e-5f) atomicAdd(&ctr->pad[2], 1u);
-                                    if (fabsf(d1[k] - d2) > band) {
+                                    if (fabsf(d1k - d2) > band) {
                                         atomicAdd(&ctr->pad[0], 1u);
                                         atomicMax(&ctr->pad[3], (uint32_t)(sqrtf(vx * vx + vy * vy + vz * vz) / sqrtf(g.r2) * 1000.f));
                                         const float ux = c.x - ox, uy = c.y - oy, uz = c.z - oz;
@@ -1286,29 +1294,26 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                         }
                     }
 #endif
-                    if (__ballot(amin < band)) {   // rare: some pair of this block lies inside the band
+                    if (__ballot(amin < g.dband)) {   // rare: some pair of this block lies inside the band
 #pragma unroll
                         for (int k = 0; k < 16; ++k) {
                             const uint32_t rk = (uint32_t)((k & 3) + 8 * (k >> 2) + 4 * half);
-                            const bool need = fabsf(g.r2 - d1[k]) < band;   // (far slots are never inside the band: a real candidate)
+                            const bool need = fabsf(d1[k]) < g.dband;   // (far slots are never inside the band: a real candidate)
                             if (__ballot(need)) {
                                 if (need) {
                                     const float4 c = spts4[c0 + p + rk];
                                     const float dx = c.x - gq[gi][0], dy = c.y - gq[gi][1], dz = c.z - gq[gi][2];
                                     // FLANN L2_Simple: every product and sum rounded, in this order; strict d2 < r2
                                     const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-                                    const float wk = d2 < g.r2 ? 1.0f : 0.0f;
-                                    if (k & 1) wv[k >> 1].y = wk; else wv[k >> 1].x = wk;
+                                    const uint32_t wk = d2 < g.r2 ? 0x3F80u : 0u;
+                                    pw[k >> 1] = (k & 1) ? ((pw[k >> 1] & 0x0000FFFFu) | (wk << 16)) : ((pw[k >> 1] & 0xFFFF0000u) | wk);
                                 }
                             }
                         }
                     }
                     union { bf16x8 v; uint32_t u[4]; } b0, b1;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        b0.u[k] = pack_hi16(__float_as_uint(wv[k].y), __float_as_uint(wv[k].x));
-                        b1.u[k] = pack_hi16(__float_as_uint(wv[4 + k].y), __float_as_uint(wv[4 + k].x));
-                    }
+                    for (int k = 0; k < 4; ++k) { b0.u[k] = pw[k]; b1.u[k] = pw[4 + k]; }
                     // ---- moment MFMA: k order of step s = the candidate order of d1's registers 8s .. 8s+7
                     acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m0.v, b0.v, acc[gi], 0, 0, 0);
                     acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m1.v, b1.v, acc[gi], 0, 0, 0);
