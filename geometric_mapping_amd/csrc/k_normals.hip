@@ -1339,8 +1339,15 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
 #pragma unroll
         for (int m = 0; m < 9; ++m) mom[1 + m] = (frow(1 + 3 * m) + frow(2 + 3 * m)) + frow(3 + 3 * m);
 
-        const bool vox_ok = emit_normal(active, q, mom, vd, normals4, counts, qn, stat_t0, A.valid8);
-        if (vd.enabled) voxel_sums(vox_ok, q, vd, vox_table);
+        // The query is read again here (an L2 hit) rather than kept in registers across the whole candidate stream: the
+        // kernel sits at its 128-VGPR budget and everything live across the loop that the loop does not use was being
+        // spilled once per tile -- 50 MB of scratch writes per launch.  (The index goes through an empty asm so that the
+        // compiler cannot tell it is the load it already has.)
+        uint32_t qidx_e = qs + (active ? (uint32_t)lane : qn - 1u);
+        asm volatile("" : "+v"(qidx_e));
+        const float4 qe = spts4[qidx_e];
+        const bool vox_ok = emit_normal(active, qe, mom, vd, normals4, counts, qn, stat_t0, A.valid8);
+        if (vd.enabled) voxel_sums(vox_ok, qe, vd, vox_table);
     }
 }
 
@@ -1381,6 +1388,11 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals_m(NormalsAr
 
 // THE production kernel: distances AND moments on the matrix cores (k_normals_m = GM_NORMALS_IMPL=auto0 keeps the
 // predicate on the VALU: 13 % slower alone, 4 % slower per step with three frames in flight; DESIGN.md par. 4)
+// LOOP = false: the grid holds a wave for every tile the frame can have (the usual launch) and a wave takes exactly one.
+// The grid-stride loop of the capped launch (frames beyond ~16 M points) is a separate instantiation on purpose: inside
+// a loop the compiler hoists every tile-invariant (lane patterns, constants) out of it and, at the 128-VGPR budget, then
+// spills them -- once per wave, i.e. once per tile: 80 MB of scratch writes per 1 M-point launch.
+template <bool LOOP>
 __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs A, uint32_t mx_min_candidates)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][(kMdWaveLdsBytes + 15) / 16 * 16];
@@ -1393,8 +1405,12 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs
     uint32_t ntiles = A.ctr->n_tiles;
     if (ntiles > A.tiles_cap) ntiles = A.tiles_cap;
     const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
-    for (uint32_t t = wave_id; t < ntiles; t += n_waves)
-        normals_tile_mxd(A, lds[threadIdx.x / kWave], A.tiles[t], mx_min_candidates);
+    if (LOOP) {
+        for (uint32_t t = wave_id; t < ntiles; t += n_waves)
+            normals_tile_mxd(A, lds[threadIdx.x / kWave], A.tiles[t], mx_min_candidates);
+    } else if (wave_id < ntiles) {
+        normals_tile_mxd(A, lds[threadIdx.x / kWave], A.tiles[wave_id], mx_min_candidates);
+    }
 }
 
 // the all-VALU formulation of every tile (GM_NORMALS_IMPL=valu: A/B measurements and the cross-check in tests)
@@ -1437,12 +1453,13 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     // one wave per tile: four tiles per block
     const uint32_t mt = max_tiles(n_cap, g);
     uint32_t nb = (mt + kNrWaves - 1) / kNrWaves;
+    bool capped = false;
     {
         // one wave per tile up to 65 536 blocks (262 144 tiles: a ~16 M-point frame), grid-stride beyond that.
         // GM_NORMALS_BLOCKS lowers the cap: tests use it to force the grid-stride path on a small frame.
         static const char *e = getenv("GM_NORMALS_BLOCKS");
         const uint32_t cap = e ? (uint32_t)atoi(e) : 65536u;
-        if (nb > cap) nb = cap;
+        if (nb > cap) { nb = cap; capped = true; }
     }
     // blocks per XCD chunk (0 = plain round-robin).  Measured on the 1 M frame: 32 keeps the kernel time of the plain
     // mapping with 29 % less L2 fill traffic; one contiguous eighth per XCD fetches 36 % less but runs 4 % longer
@@ -1463,7 +1480,8 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     // a trailing 0 (auto0 / mfma0) keeps the neighbour predicate on the VALU (k_normals_m: moments only on the matrix cores)
     const bool dist_on_mx = !(impl && strchr(impl, '0'));
     if (mx_min == 0xFFFFFFFFu) hipLaunchKernelGGL(k_normals_valu, dim3(nb), dim3(kNrThreads), 0, s, na);
-    else if (dist_on_mx) hipLaunchKernelGGL(k_normals, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
+    else if (dist_on_mx && capped) hipLaunchKernelGGL(k_normals<true>, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
+    else if (dist_on_mx) hipLaunchKernelGGL(k_normals<false>, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
     else hipLaunchKernelGGL(k_normals_m, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
     hipEventRecord(sl.ev_k1, s);
 }

@@ -19,7 +19,7 @@ for d in ("pmc_valu_a", "pmc_valu_b", "pmc_valu_c"):
     for f in glob.glob(os.path.join(out_dir, d, "**", "*counter_collection.csv"), recursive=True):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"].startswith("gm::k_normals"):
+            if "gm::k_normals<" in r["Kernel_Name"] or r["Kernel_Name"].startswith("gm::k_normals("):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             c[k] = sum(v) / len(v)

@@ -21,6 +21,10 @@ for r in csv.DictReader(open(stats)):
 
 # kernel -> (reference step, algorithmic bytes, bytes really moved)
 rows = {
+    # round 2, second half: the compactions are single launches (chained scan); the NaN-normal removal also sums the
+    # scatter-matrix terms of the survivors (getLocalFrame needs no pass of its own: its 16 B per point are not read again)
+    "gm::k_compact<gm::CropPred, gm::CropEmit>": ("fromROSMsg + CropBox (order-preserving), one launch", 12 * n_in + 12 * n_c, 16 * n_in + 16 * n_c + 4 * n_c),
+    "gm::k_compact<gm::ValidPred, gm::ValidEmit>": ("removeNaNNormals + ExtractIndices + getLocalFrame partial sums, one launch", 28 * n_c + 28 * n_v, n_c + 32 * n_v + 32 * n_v),
     "gm::k_compact_count<gm::CropPred>": ("CropBox predicate pass", 12 * n_in, 12 * n_in),
     "gm::k_compact_scatter<gm::CropPred, gm::CropEmit>": ("CropBox copy (order-preserving)", 12 * n_in + 12 * n_c, 12 * n_in + 16 * n_c + 4 * n_c),
     # since round 2 the predicate is a 1-byte flag per point written by k_normals (the 12 B of the normal it stands for are
@@ -32,7 +36,9 @@ rows = {
     "gm::k_label<1>": ("cylinder inlier labelling", 12 * n_v + n_v, 16 * n_v + 2 * n_v),
     # frame pipeline since round 2: the label passes also sum their segment's moments (one pass less over the cloud);
     # algorithmic = labelling (12 + 1 B per point) + the per-segment covariance (12 B per point, SURVEY par. 8d)
-    "gm::k_label<0, 1>": ("plane inlier labelling + plane-segment moments", 12 * n_v + n_v + 12 * n_v, 16 * n_v + n_v),
+    # (every array counted once: the moments reuse the points the labelling reads; the cylinder's normal moments read the
+    #  normals of its inliers -- counted for every point, an upper bound)
+    "gm::k_label<0, 1>": ("plane inlier labelling + plane-segment moments", 12 * n_v + n_v, 16 * n_v + n_v),
     "gm::k_label<1, 1>": ("cylinder inlier labelling + cylinder-segment moments (normals of the inliers)", 12 * n_v + n_v + 12 * n_v, 16 * n_v + 2 * n_v + 16 * n_v),
     "gm::k_segment_moments": ("per-segment covariance (points + normals of one label)", 24 * n_v + n_v, 32 * n_v + n_v),
     "gm::k_frame_moments": ("per-segment covariance, both segments in one pass (labels + points; normals of cylinder inliers)", 12 * n_v + n_v, 32 * n_v + n_v),
