@@ -58,25 +58,64 @@ void free_slot_buffers(Slot &sl)
 // every radius >= 1e-15 m (and the radius 0, "no neighbours", is handled exactly as well).
 static bool radius_ok(double r) { return std::isfinite(r) && (r == 0.0 || (r >= 1e-15 && r <= 1e15)); }
 
-GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, float ez, double radius)
+// Rows per radius.  Finer y/z rows cut the candidate stream when a tile (64 consecutive points of one row) is short
+// against the radius -- many neighbours per point -- and lengthen it otherwise (tools/sim_normals_grid.py: at k ~ 256 the
+// streamed pair slots grow 14 % with D = 2, at k ~ 5 100 they shrink 19 / 27 / 31 % with D = 2 / 3 / 4).  The neighbour
+// count is not known before the frame is processed; the estimate is the count a uniform fill of the box would give,
+// times ten (a surface scan concentrates its points), D = estimate / 670 (tile length <= 0.3 r).  GM_NORMALS_ROWS=1..4
+// overrides; only the matrix-core kernel knows D > 1.
+static int rows_per_radius(double radius, float ex, float ey, float ez, uint32_t n_points)
+{
+    static const char *e = getenv("GM_NORMALS_ROWS");
+    static const char *impl = getenv("GM_NORMALS_IMPL");
+    if (impl && !(impl[0] == 'a' || impl[0] == 'm') ) return 1;
+    if (impl && strchr(impl, '0')) return 1;
+    if (e) { const int d = atoi(e); return d < 1 ? 1 : (d > 4 ? 4 : d); }
+    const double vol = (double)ex * ey * ez;
+    if (!(vol > 0.0) || n_points == 0) return 1;
+    const double k_est = 10.0 * (double)n_points * (4.18879 * radius * radius * radius) / vol;
+    const int d = (int)(k_est / 670.0);
+    return d < 1 ? 1 : (d > 4 ? 4 : d);
+}
+
+GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, float ez, double radius, uint32_t n_points)
 {
     GridParams g;
     float ext = fmaxf(ex, fmaxf(ey, ez));
-    float h = (float)radius * 1.001f;
-    if (!(h > 1e-9f)) h = 1e-9f;
-    if (h < ext / 1023.0f) h = ext / 1023.0f;
+    float hr = (float)radius * 1.001f;     // the radius-sized edge: x binning and the error band are relative to it
+    if (!(hr > 1e-9f)) hr = 1e-9f;
+    if (hr < ext / 1023.0f) hr = ext / 1023.0f;
+    int D = rows_per_radius(radius, ex, ey, ez, n_points);
+    while (D > 1 && hr / (float)D < ext / 1023.0f) --D;   // <= 1024 rows per axis
+    const float h = hr / (float)D;         // y/z cell edge
+    g.D = D;
     g.ox = lo_x; g.oy = lo_y; g.oz = lo_z;
     g.inv_h = 1.0f / h;
     auto dim = [&](float e, float inv, int cap) { int n = (int)floorf(e * inv) + 1; return n < 1 ? 1 : (n > cap ? cap : n); };
     g.ny = dim(ey, g.inv_h, 1024); g.nz = dim(ez, g.inv_h, 1024);
-    const int nxc = dim(ex, g.inv_h, 1024);
+    const float inv_hr = 1.0f / hr;
+    const int nxc = dim(ex, inv_hr, 1024);
     // x is binned 64x finer than y/z (measured on the 1 M frame: 8x 0.370 ms, 16x 0.345, 32x 0.337, 64x 0.328,
     // 128x 0.329 for k_normals; beyond that the extra key bits cost the sort more than the windows gain)
     int fine = 64;
     while (fine > 1 && (uint64_t)g.ny * g.nz * (uint64_t)(nxc * fine + fine) >= (1ull << 31)) fine >>= 1;
-    g.inv_hx = g.inv_h * (float)fine;
+    g.inv_hx = inv_hr * (float)fine;
     g.nx = dim(ex, g.inv_hx, 1024 * fine);
     g.xreach = fine + 1;
+    // per-row window half-widths.  A candidate in the row (a, b) cells away from the query's row is further than
+    // gap = (|a| - 1) h resp. (|b| - 1) h from it in y resp. z, so |dx| < sqrt(r^2 - gap_y^2 - gap_z^2); two fine cells
+    // whose points are closer than w in x differ by at most floor(w * inv_hx) + 1 in their index (+1 spare, as before).
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b) {
+            g.reach[a][b] = 0;
+            if (a > D || b > D) continue;
+            const double gy = a > 1 ? (a - 1) * (double)h : 0.0, gz = b > 1 ? (b - 1) * (double)h : 0.0;
+            const double w2 = radius * radius - gy * gy - gz * gz;
+            if (w2 <= 0.0) continue;
+            int rc = (int)floor(sqrt(w2) * (double)g.inv_hx * (1.0 + 1e-6)) + 2;
+            if (rc > g.xreach) rc = g.xreach;
+            g.reach[a][b] = (int16_t)rc;
+        }
     g.r2 = (float)(radius * radius);  // KdTreeFLANN::radiusSearch: static_cast<float>(radius*radius)
     {
         int e = 0;
@@ -91,7 +130,7 @@ GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, flo
         (void)frexpf(cmax > 1e-30f ? cmax : 1e-30f, &e);   // cmax = m * 2^e, m in [0.5, 1): ulp(cmax) = 2^(e - 24)
         g.snap = ldexpf(1.0f, e - 24 < -120 ? -120 : e - 24);
         static const char *bs = getenv("GM_MX_BAND_SCALE");   // experiments only
-        g.band = 2.0e-5f * h * h * (bs ? (float)atof(bs) : 1.0f);
+        g.band = 2.0e-5f * hr * hr * (bs ? (float)atof(bs) : 1.0f);
         int be = 0;
         (void)frexpf(1.0f / g.band, &be);                    // 1/band = m * 2^be, m in [0.5, 1)  =>  2^be >= 1/band
         g.dscale = ldexpf(1.0f, be > 60 ? 60 : be);
@@ -275,7 +314,7 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     // Eigen::Vector4f(-bound, ...) : double -> float (src/tunnel_processing.cpp:43-44)
     const float lo = (float)(-cf.boxFilterBound), hi = (float)cf.boxFilterBound;
     const float ext = hi - lo;
-    const GridParams g = make_grid(lo, lo, lo, ext, ext, ext, cf.neighborRadius);
+    const GridParams g = make_grid(lo, lo, lo, ext, ext, ext, cf.neighborRadius, n);
     VoxDense vd;
     memset(&vd, 0, sizeof(vd));
     vd.own_lo = (float)ctx->own_lo;
@@ -768,7 +807,7 @@ gm_status gm_chop_cloud(gm_ctx *ctx, const gm_cloud *cloud, double bound, float 
     st = make_rows(ctx, cloud, dev_rows, rows);
     if (st != GM_OK) return st;
     const float lo = (float)(-bound), hi = (float)bound;
-    const GridParams g = make_grid(lo, lo, lo, hi - lo, hi - lo, hi - lo, ctx->cfg.neighborRadius);
+    const GridParams g = make_grid(lo, lo, lo, hi - lo, hi - lo, hi - lo, ctx->cfg.neighborRadius, n);
     launch_crop(rows, n, lo, hi, g, sl, sl.stream);
     uint32_t m = 0;
     GM_HIP(ctx, hipMemcpyAsync(&m, &sl.ctr->n_cropped, 4, hipMemcpyDeviceToHost, sl.stream));
@@ -806,7 +845,7 @@ gm_status gm_get_normals_stage(gm_ctx *ctx, const float *xyz, uint32_t n, double
     RowLayout rows;
     st = make_rows(ctx, &c, sl.d_raw, rows);
     if (st != GM_OK) return st;
-    const GridParams g = make_grid(mn[0], mn[1], mn[2], mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], radius);
+    const GridParams g = make_grid(mn[0], mn[1], mn[2], mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2], radius, n);
     const float big = std::numeric_limits<float>::max();
     launch_crop(rows, n, -big, big, g, sl, sl.stream);  // drops non-finite rows only
     VoxDense vd_off;

@@ -57,6 +57,10 @@ struct GridParams {
     float snap;         // power of two >= one ulp of the largest coordinate of the grid box: tile origins of the
                         // matrix-core kernel are multiples of it, which makes point - origin exact up to the rounding of a
                         // radius-sized number
+    int32_t D;          // y/z rows per radius (1 .. 4): the cells are 1.001 r / D wide in y and z, a tile's candidates lie
+                        // in the (2D+1)^2 rows around its own.  D > 1 pays when a tile is short against the radius (many
+                        // neighbours per point): the far rows need a shorter x-window, sqrt(r^2 - gap_y^2 - gap_z^2).
+    int16_t reach[5][5];// [|row offset y|][|row offset z|]: fine x cells that cover that window half-width; 0 = no row
     float dscale;       // power of two >= 1 / band: the distance MFMA of k_normals computes T = (r2 - d2) * dscale, so that
                         // one v_cvt_pk_bf16_f32 with clamp turns two of them into two 0/1 weights (every T in (0, 1) lies
                         // inside the band and is re-evaluated exactly)

@@ -1048,20 +1048,27 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             }
             return;
         }
-        // ---- candidate windows: lane i < 18 finds both ends of the window of (row i / 2, group i % 2)
+        // ---- candidate windows.  The tile's candidates lie in the (2D+1)^2 rows around its own; they are taken in passes
+        // of up to 32 rows: lane i finds both ends of the window of (row i / 2 of the pass, group i % 2).  D = 1 (the
+        // usual grid): 9 rows, one pass.
+        const int side = 2 * g.D + 1, nrows_all = side * side;
         uint32_t sb = 0, se = 0;
-        {
-            const int slot = lane < 9 * kMxGroups ? lane : 0;
-            const int r = slot / kMxGroups, gg = slot % kMxGroups;
+        int nrows = 0;   // rows of the current pass
+        auto find_windows = [&](int row0) {
+            nrows = nrows_all - row0 < 32 ? nrows_all - row0 : 32;
+            sb = 0; se = 0;
+            const int r = row0 + (lane >> 1), gg = lane & 1;
             const int lo_fx = __shfl(fxl, gg * kMxGroupLanes, kWave);
             const int hi_fx = __shfl(fxl, gg * kMxGroupLanes + kMxGroupLanes - 1, kWave);
-            const int yy = cy + (r % 3) - 1, zz = cz + (r / 3) - 1;
-            if (lane < 9 * kMxGroups && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+            const int a = (r % side) - g.D, b = (r / side) - g.D;
+            const int yy = cy + a, zz = cz + b;
+            const int reach = (lane >> 1) < nrows ? (int)g.reach[a < 0 ? -a : a][b < 0 ? -b : b] : 0;
+            if (reach > 0 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
                 const uint32_t nrow = (uint32_t)(zz * g.ny + yy);
                 const uint2 rb = row_bounds[nrow];
                 const uint32_t rbk = nrow * (uint32_t)g.nx;
-                const int xa = lo_fx > g.xreach ? lo_fx - g.xreach : 0;
-                const int xb = hi_fx + g.xreach < g.nx - 1 ? hi_fx + g.xreach : g.nx - 1;
+                const int xa = lo_fx > reach ? lo_fx - reach : 0;
+                const int xb = hi_fx + reach < g.nx - 1 ? hi_fx + reach : g.nx - 1;
                 const uint32_t key_b = rbk + (uint32_t)xa, key_e = rbk + (uint32_t)xb + 1u;
                 uint32_t lo1 = rb.x, hi1 = rb.y, lo2 = rb.x, hi2 = rb.y;
                 while (lo1 < hi1 || lo2 < hi2) {
@@ -1072,13 +1079,14 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                 }
                 sb = lo1; se = lo2;
             }
-        }
+        };
+        find_windows(0);
         // Thin neighbourhoods (fewer than min_candidates candidates in the first group's windows) take the direct path
         // below: nothing to amortise the feature staging over, and the few-point covariances of a sparse cloud are
         // near-degenerate, where offsets from the query itself (|offset| < r) in fp64 keep more than offsets from a
-        // tile origin through bf16 features do.
-        bool thin;
-        {
+        // tile origin through bf16 features do.  (Only on the usual grid: finer rows are chosen for dense frames.)
+        bool thin = false;
+        if (g.D == 1) {
             uint32_t wl = (lane < 9 * kMxGroups && (lane % kMxGroups) == 0) ? se - sb : 0u;
             wl = (uint32_t)wave_sum((unsigned long long)wl);
             thin = wl < min_candidates;
@@ -1140,11 +1148,11 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         uint32_t nc0 = 0, nlen = 0;
         auto seek = [&](int r, uint32_t c) {
             nlen = 0;
-            while (r < 9) {
+            while (r < nrows) {
                 const uint32_t e = row_end(r);
                 if (c < e) { nr = r; nc0 = c; nlen = (e - c < (uint32_t)kMdChunk) ? e - c : (uint32_t)kMdChunk; return; }
                 ++r;
-                if (r < 9) c = row_begin(r);
+                if (r < nrows) c = row_begin(r);
             }
         };
         if (thin) {
@@ -1169,6 +1177,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             if (vd.enabled) voxel_sums(vox_ok, q, vd, vox_table);
             return;
         }
+        for (int row0 = 0;;) {
         seek(0, row_begin(0));
         while (nlen) {
             const int r = nr;
@@ -1214,7 +1223,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                     feat[(i >> 3) * (uint32_t)kMdOctetWords + ((i & 7u) >> 1) + 28u * 4u] = 0x71807180u;   // bf16(2^100) | bf16(2^100)
             }
             wave_lds_fence();
-            if (c0 + clen < row_end(r)) seek(r, c0 + clen); else seek(r + 1, r + 1 < 9 ? row_begin(r + 1) : 0u);
+            if (c0 + clen < row_end(r)) seek(r, c0 + clen); else seek(r + 1, r + 1 < nrows ? row_begin(r + 1) : 0u);
 #pragma unroll
             for (int gi = 0; gi < kMxGroups; ++gi) {
                 if (gi >= ngroups) break;  // wave-uniform
@@ -1319,6 +1328,10 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                     acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m1.v, b1.v, acc[gi], 0, 0, 0);
                 }
             }
+        }
+        row0 += 32;
+        if (row0 >= nrows_all) break;
+        find_windows(row0);   // the next pass of rows (finer grids only)
         }
         // ---- D[row][query]: lane (q, h) of group g holds rows (k & 3) + 8 (k >> 2) + 4 h in acc[g][k].  A lane's home
         // query is query (lane & 31) of group (lane >> 5): it keeps its own half of that group's rows and swaps the
