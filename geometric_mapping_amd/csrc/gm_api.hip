@@ -62,7 +62,7 @@ static bool radius_ok(double r) { return std::isfinite(r) && (r == 0.0 || (r >= 
 // against the radius -- many neighbours per point -- and lengthen it otherwise (tools/sim_normals_grid.py: at k ~ 256 the
 // streamed pair slots grow 14 % with D = 2, at k ~ 5 100 they shrink 19 / 27 / 31 % with D = 2 / 3 / 4).  The neighbour
 // count is not known before the frame is processed; the estimate is the count a uniform fill of the box would give,
-// times ten (a surface scan concentrates its points), D = estimate / 670 (tile length <= 0.3 r).  GM_NORMALS_ROWS=1..4
+// times ten (a surface scan concentrates its points).  GM_NORMALS_ROWS=1..4
 // overrides; only the matrix-core kernel knows D > 1.
 static int rows_per_radius(double radius, float ex, float ey, float ez, uint32_t n_points)
 {
@@ -74,8 +74,9 @@ static int rows_per_radius(double radius, float ex, float ey, float ez, uint32_t
     const double vol = (double)ex * ey * ez;
     if (!(vol > 0.0) || n_points == 0) return 1;
     const double k_est = 10.0 * (double)n_points * (4.18879 * radius * radius * radius) / vol;
-    const int d = (int)(k_est / 670.0);
-    return d < 1 ? 1 : (d > 4 ? 4 : d);
+    // measured on the 1 M-point tunnel frame (tools/sweep_rows.sh): r = 0.25 (estimate 650, true k 1 280): D = 1 / 2 / 3 / 4
+    // = 0.446 / 0.422 / 0.477 / 0.536 ms; r = 0.5 (estimate 5 200, true k 5 100): 1.47 / 1.24 / 1.25 / 1.21 ms
+    return k_est < 400.0 ? 1 : (k_est < 2000.0 ? 2 : 4);
 }
 
 GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, float ez, double radius, uint32_t n_points)

@@ -1000,6 +1000,9 @@ __device__ __forceinline__ s4 md_tr_read(const unsigned char *p)
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)p);
 }
 
+// FINE = false: the usual grid (cells one radius wide, 3 x 3 rows: everything about rows is a compile-time constant);
+// FINE = true: y/z rows finer than the radius (GridParams::D > 1), chosen for frames with very many neighbours per point.
+template <bool FINE>
 __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned char *lds, const uint2 tile, uint32_t min_candidates)
 {
     const float4 *__restrict__ spts4 = A.spts4;
@@ -1051,7 +1054,8 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         // ---- candidate windows.  The tile's candidates lie in the (2D+1)^2 rows around its own; they are taken in passes
         // of up to 32 rows: lane i finds both ends of the window of (row i / 2 of the pass, group i % 2).  D = 1 (the
         // usual grid): 9 rows, one pass.
-        const int side = 2 * g.D + 1, nrows_all = side * side;
+        const int gD = FINE ? g.D : 1;
+        const int side = 2 * gD + 1, nrows_all = side * side;
         uint32_t sb = 0, se = 0;
         int nrows = 0;   // rows of the current pass
         auto find_windows = [&](int row0) {
@@ -1060,9 +1064,9 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             const int r = row0 + (lane >> 1), gg = lane & 1;
             const int lo_fx = __shfl(fxl, gg * kMxGroupLanes, kWave);
             const int hi_fx = __shfl(fxl, gg * kMxGroupLanes + kMxGroupLanes - 1, kWave);
-            const int a = (r % side) - g.D, b = (r / side) - g.D;
+            const int a = (r % side) - gD, b = (r / side) - gD;
             const int yy = cy + a, zz = cz + b;
-            const int reach = (lane >> 1) < nrows ? (int)g.reach[a < 0 ? -a : a][b < 0 ? -b : b] : 0;
+            const int reach = (lane >> 1) < nrows ? (FINE ? (int)g.reach[a < 0 ? -a : a][b < 0 ? -b : b] : g.xreach) : 0;
             if (reach > 0 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
                 const uint32_t nrow = (uint32_t)(zz * g.ny + yy);
                 const uint2 rb = row_bounds[nrow];
@@ -1086,7 +1090,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         // near-degenerate, where offsets from the query itself (|offset| < r) in fp64 keep more than offsets from a
         // tile origin through bf16 features do.  (Only on the usual grid: finer rows are chosen for dense frames.)
         bool thin = false;
-        if (g.D == 1) {
+        if (!FINE) {
             uint32_t wl = (lane < 9 * kMxGroups && (lane % kMxGroups) == 0) ? se - sb : 0u;
             wl = (uint32_t)wave_sum((unsigned long long)wl);
             thin = wl < min_candidates;
@@ -1330,7 +1334,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             }
         }
         row0 += 32;
-        if (row0 >= nrows_all) break;
+        if (!FINE || row0 >= nrows_all) break;
         find_windows(row0);   // the next pass of rows (finer grids only)
         }
         // ---- D[row][query]: lane (q, h) of group g holds rows (k & 3) + 8 (k >> 2) + 4 h in acc[g][k].  A lane's home
@@ -1405,7 +1409,7 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals_m(NormalsAr
 // The grid-stride loop of the capped launch (frames beyond ~16 M points) is a separate instantiation on purpose: inside
 // a loop the compiler hoists every tile-invariant (lane patterns, constants) out of it and, at the 128-VGPR budget, then
 // spills them -- once per wave, i.e. once per tile: 80 MB of scratch writes per 1 M-point launch.
-template <bool LOOP>
+template <bool LOOP, bool FINE>
 __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs A, uint32_t mx_min_candidates)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][(kMdWaveLdsBytes + 15) / 16 * 16];
@@ -1420,9 +1424,9 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs
     const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
     if (LOOP) {
         for (uint32_t t = wave_id; t < ntiles; t += n_waves)
-            normals_tile_mxd(A, lds[threadIdx.x / kWave], A.tiles[t], mx_min_candidates);
+            normals_tile_mxd<FINE>(A, lds[threadIdx.x / kWave], A.tiles[t], mx_min_candidates);
     } else if (wave_id < ntiles) {
-        normals_tile_mxd(A, lds[threadIdx.x / kWave], A.tiles[wave_id], mx_min_candidates);
+        normals_tile_mxd<FINE>(A, lds[threadIdx.x / kWave], A.tiles[wave_id], mx_min_candidates);
     }
 }
 
@@ -1493,8 +1497,16 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     // a trailing 0 (auto0 / mfma0) keeps the neighbour predicate on the VALU (k_normals_m: moments only on the matrix cores)
     const bool dist_on_mx = !(impl && strchr(impl, '0'));
     if (mx_min == 0xFFFFFFFFu) hipLaunchKernelGGL(k_normals_valu, dim3(nb), dim3(kNrThreads), 0, s, na);
-    else if (dist_on_mx && capped) hipLaunchKernelGGL(k_normals<true>, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
-    else if (dist_on_mx) hipLaunchKernelGGL(k_normals<false>, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
+    else if (dist_on_mx) {
+        const bool fine = g.D > 1;
+        if (capped) {
+            if (fine) hipLaunchKernelGGL((k_normals<true, true>), dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
+            else hipLaunchKernelGGL((k_normals<true, false>), dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
+        } else {
+            if (fine) hipLaunchKernelGGL((k_normals<false, true>), dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
+            else hipLaunchKernelGGL((k_normals<false, false>), dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
+        }
+    }
     else hipLaunchKernelGGL(k_normals_m, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
     hipEventRecord(sl.ev_k1, s);
 }
