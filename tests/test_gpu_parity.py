@@ -495,12 +495,14 @@ def test_frame_smaller_than_capacity_with_another_sort_layout(gm):
     assert np.array_equal(nrm, ref_n, equal_nan=True)
 
 
-@pytest.mark.parametrize("impl", ["valu", "mfma", "auto0", "mfma0"])
+@pytest.mark.parametrize("impl", ["valu", "mfma", "auto0", "mfma0", "rows2", "rows4"])
 def test_every_formulation_of_the_neighbourhood_kernel_finds_the_same_neighbours(impl):
     """GM_NORMALS_IMPL (read once per process -> child processes): the all-VALU kernel, the production kernel (distances
     and moments on the matrix cores, exact re-evaluation inside a band) forced onto every tile, and the variant that
     keeps the neighbour predicate on the VALU must report the neighbour counts and NaN pattern of the default build bit for bit, and normals
-    within 1e-5 rad -- on a dense frame and on a sparse one (thin neighbourhoods, long tiles)."""
+    within 1e-5 rad -- on a dense frame and on a sparse one (thin neighbourhoods, long tiles).  rows2 / rows4: the same for
+    the fine-row mode of the production kernel (GM_NORMALS_ROWS: y/z cells r/2 and r/4 wide, 25 / 81 rows per tile in
+    passes, per-row x-reach), forced onto frames it would not be chosen for."""
     import subprocess, sys, tempfile, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (
@@ -520,7 +522,10 @@ def test_every_formulation_of_the_neighbourhood_kernel_finds_the_same_neighbours
         for tag in (None, impl):
             env = dict(os.environ)
             env.pop("GM_NORMALS_IMPL", None)
-            if tag:
+            env.pop("GM_NORMALS_ROWS", None)
+            if tag and tag.startswith("rows"):
+                env["GM_NORMALS_ROWS"] = tag[4:]
+            elif tag:
                 env["GM_NORMALS_IMPL"] = tag
             f = os.path.join(d, (tag or "default") + ".npz")
             r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=300)
