@@ -1405,11 +1405,12 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals_m(NormalsAr
 
 // THE production kernel: distances AND moments on the matrix cores (k_normals_m = GM_NORMALS_IMPL=auto0 keeps the
 // predicate on the VALU: 13 % slower alone, 4 % slower per step with three frames in flight; DESIGN.md par. 4)
-// LOOP = false: the grid holds a wave for every tile the frame can have (the usual launch) and a wave takes exactly one.
-// The grid-stride loop of the capped launch (frames beyond ~16 M points) is a separate instantiation on purpose: inside
-// a loop the compiler hoists every tile-invariant (lane patterns, constants) out of it and, at the 128-VGPR budget, then
-// spills them -- once per wave, i.e. once per tile: 80 MB of scratch writes per 1 M-point launch.
-template <bool LOOP, bool FINE>
+// A wave takes the tile of its id; tiles beyond the grid (the grid is capped at 65 536 blocks: frames beyond ~8 M points,
+// or GM_NORMALS_BLOCKS in tests) are walked by a second, looped copy of the tile code.  Two copies on purpose: inside a
+// loop the compiler hoists every tile-invariant (lane patterns, constants) out of it and, at the 128-VGPR budget, then
+// spills them -- once per wave, i.e. once per tile: 80 MB of scratch writes per 1 M-point launch when the loop was the
+// only copy.  The straight-line copy spills nothing; the looped one is only entered by the frames that need it.
+template <bool FINE>
 __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs A, uint32_t mx_min_candidates)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][(kMdWaveLdsBytes + 15) / 16 * 16];
@@ -1422,12 +1423,10 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs
     uint32_t ntiles = A.ctr->n_tiles;
     if (ntiles > A.tiles_cap) ntiles = A.tiles_cap;
     const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
-    if (LOOP) {
-        for (uint32_t t = wave_id; t < ntiles; t += n_waves)
+    if (wave_id < ntiles) normals_tile_mxd<FINE>(A, lds[threadIdx.x / kWave], A.tiles[wave_id], mx_min_candidates);
+    if (ntiles > n_waves && wave_id != 0xFFFFFFFFu)
+        for (uint32_t t = wave_id + n_waves; t < ntiles; t += n_waves)
             normals_tile_mxd<FINE>(A, lds[threadIdx.x / kWave], A.tiles[t], mx_min_candidates);
-    } else if (wave_id < ntiles) {
-        normals_tile_mxd<FINE>(A, lds[threadIdx.x / kWave], A.tiles[wave_id], mx_min_candidates);
-    }
 }
 
 // the all-VALU formulation of every tile (GM_NORMALS_IMPL=valu: A/B measurements and the cross-check in tests)
@@ -1470,13 +1469,12 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     // one wave per tile: four tiles per block
     const uint32_t mt = max_tiles(n_cap, g);
     uint32_t nb = (mt + kNrWaves - 1) / kNrWaves;
-    bool capped = false;
     {
         // one wave per tile up to 65 536 blocks (262 144 tiles: a ~16 M-point frame), grid-stride beyond that.
         // GM_NORMALS_BLOCKS lowers the cap: tests use it to force the grid-stride path on a small frame.
         static const char *e = getenv("GM_NORMALS_BLOCKS");
         const uint32_t cap = e ? (uint32_t)atoi(e) : 65536u;
-        if (nb > cap) { nb = cap; capped = true; }
+        if (nb > cap) nb = cap;
     }
     // blocks per XCD chunk (0 = plain round-robin).  Measured on the 1 M frame: 32 keeps the kernel time of the plain
     // mapping with 29 % less L2 fill traffic; one contiguous eighth per XCD fetches 36 % less but runs 4 % longer
@@ -1498,14 +1496,8 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     const bool dist_on_mx = !(impl && strchr(impl, '0'));
     if (mx_min == 0xFFFFFFFFu) hipLaunchKernelGGL(k_normals_valu, dim3(nb), dim3(kNrThreads), 0, s, na);
     else if (dist_on_mx) {
-        const bool fine = g.D > 1;
-        if (capped) {
-            if (fine) hipLaunchKernelGGL((k_normals<true, true>), dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
-            else hipLaunchKernelGGL((k_normals<true, false>), dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
-        } else {
-            if (fine) hipLaunchKernelGGL((k_normals<false, true>), dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
-            else hipLaunchKernelGGL((k_normals<false, false>), dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
-        }
+        if (g.D > 1) hipLaunchKernelGGL(k_normals<true>, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
+        else hipLaunchKernelGGL(k_normals<false>, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
     }
     else hipLaunchKernelGGL(k_normals_m, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
     hipEventRecord(sl.ev_k1, s);
