@@ -292,7 +292,7 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     gm_status st = check_layout(ctx, cloud);
     if (st != GM_OK) return st;
     // n == 0 still sizes the buffers for one point: every stage below may then assume non-null scratch (an empty
-    // cloud as the very first frame of a context used to reach k_compact_count with block_counts == nullptr)
+    // cloud as the very first frame of a context used to reach the compaction with a null scratch array)
     st = ensure_capacity(ctx, sl, n ? n : 1u, raw_bytes, !on_dev);
     if (st != GM_OK) return st;
     if (ctx->cfg.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER | GM_CFG_NEAREST)) {

@@ -1396,7 +1396,7 @@ __device__ __forceinline__ uint32_t normals_wave_id(const NormalsArgs &A, uint32
 __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals_m(NormalsArgs A, uint32_t mx_min_candidates)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][kWaveLdsBytes];
-    uint32_t ntiles = A.ctr->n_tiles;   // final before the launch (k_build_tiles)
+    uint32_t ntiles = A.ctr->n_tiles;   // final before the launch (k_rows_and_tiles)
     if (ntiles > A.tiles_cap) ntiles = A.tiles_cap;
     const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
     for (uint32_t t = wave_id; t < ntiles; t += n_waves)   // every wave reaches the end: the list is final
