@@ -218,8 +218,8 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
     GM_HIP(ctx, dmalloc(sl.row_bounds, (size_t)1024 * 1024));  // make_grid caps every axis at 1024 cells
     sl.blk_cap = compact_blocks(cap > kVoxDenseMaxCells ? cap : kVoxDenseMaxCells) + 1;
     GM_HIP(ctx, dmalloc(sl.tile_partials, (size_t)compact_blocks(cap) * 6));
-    GM_HIP(ctx, dmalloc(sl.blk, (size_t)sl.blk_cap));
-    GM_HIP(ctx, hipMemsetAsync(sl.blk, 0, sizeof(unsigned long long) * (size_t)sl.blk_cap, sl.stream));
+    GM_HIP(ctx, dmalloc(sl.blk, (size_t)sl.blk_cap + 1));  // + the ticket word
+    GM_HIP(ctx, hipMemsetAsync(sl.blk, 0, sizeof(unsigned long long) * ((size_t)sl.blk_cap + 1), sl.stream));
     sl.scan_epoch = 0;
     sl.sort.hist_cap = radix_hist_entries(cap);
     GM_HIP(ctx, dmalloc(sl.sort.hist, sl.sort.hist_cap));

@@ -12,45 +12,38 @@
 // own (INCLUSIVE).  The input is read once; there is no count pass and no scan
 // kernel.
 //
-// Progress without a ticket counter: the grid is capped at kCpMaxGrid blocks --
-// no more than fit on the chip together (256 threads, <= 128 VGPRs by the launch
-// bounds, a few hundred bytes of LDS: 4 blocks per CU x 256 CUs) -- and block b
-// takes tiles b, b + grid, b + 2 grid, ...  A block only ever waits for lower
-// tiles; the owner of the lowest unfinished tile waits for nothing, and it is
-// either running or will be given a slot, because this launch can never fill
-// every slot with waiting blocks.  (An atomic ticket per block, the usual
-// alternative, is one same-address atomic per block in front of everything else.)
-// A record is one 64-bit word [epoch:30 | state:2 | value:32] written and read
-// with single agent-scope atomics; the epoch (a per-slot launch counter, never 0)
-// makes the records of earlier launches read as "not there yet", so the array
-// is never cleared (zeroed once at allocation).
+// Progress: tiles are handed out by an atomic ticket, so a block only ever waits for tiles whose blocks are already
+// running -- whatever else shares the chip.  (Taking the tile from blockIdx instead saves the ticket's ~4 us of
+// same-address atomics per launch and was measured; but then a resident block can wait for one that has no slot yet, and
+// with several compactions in flight -- frames on other streams, other processes -- the waiting blocks of different
+// launches could fill an XCD between them and keep each other's missing blocks out for good.  A hang is not a price.)
+// The blocks are 512 threads wide to halve the number of tickets.
+// A record is one 64-bit word [epoch:30 | state:2 | value:32] written and read with single agent-scope atomics; the
+// epoch (a per-slot launch counter, never 0) makes the records of earlier launches read as "not there yet", so the array
+// is never cleared (zeroed once at allocation).  The block that takes the last ticket resets the ticket word for the
+// next launch on the stream.
 #pragma once
 
 #include "gm_device.hpp"
 
 namespace gm {
 
-constexpr int kCpThreads = 256;
+constexpr int kCpThreads = 512;
 constexpr int kCpItems = 8;
 constexpr int kCpTile = kCpThreads * kCpItems;  // points per tile
 constexpr int kCpWaves = kCpThreads / kWave;
-constexpr uint32_t kCpMaxGrid = 1024;           // co-resident by construction (see above)
 
 inline uint32_t compact_blocks(uint32_t n) { return (n + kCpTile - 1) / kCpTile; }  // tiles of n points
-inline uint32_t compact_grid(uint32_t n)
-{
-    const uint32_t t = compact_blocks(n);
-    return t < kCpMaxGrid ? t : kCpMaxGrid;
-}
+inline uint32_t compact_grid(uint32_t n) { return compact_blocks(n); }               // one block per tile
 
 // Pred: __device__ bool operator()(uint32_t i) const
 // Emit: __device__ void operator()(uint32_t src, uint32_t dst); static constexpr bool kHasFinish; when true,
 //       __device__ void finish(uint32_t tile) is called by every thread of the block once per tile that held input,
 //       after the tile's last emit (per-tile state lives in the functor; finish() resets it)
-// The element count is *n_ptr (device-resident) or n_host; the grid is compact_grid(capacity).  The number of survivors
+// The element count is *n_ptr (device-resident) or n_host; the grid is compact_grid(capacity): a block per tile.  The number of survivors
 // goes to total_out / total_out2 (either may be null) -- also when it is 0.
 template <class Pred, class Emit>
-__global__ __launch_bounds__(kCpThreads, 4) void k_compact(Pred pred, Emit emit, const uint32_t *__restrict__ n_ptr,
+__global__ __launch_bounds__(kCpThreads) void k_compact(Pred pred, Emit emit, const uint32_t *__restrict__ n_ptr,
                                                             uint32_t n_host, ScanState st,
                                                             uint32_t *__restrict__ total_out,
                                                             uint32_t *__restrict__ total_out2)
@@ -62,15 +55,23 @@ __global__ __launch_bounds__(kCpThreads, 4) void k_compact(Pred pred, Emit emit,
     const uint32_t ntiles = (n + (uint32_t)kCpTile - 1u) / (uint32_t)kCpTile;
     const int w = threadIdx.x / kWave, lane = lane_id();
     const uint64_t tag = (uint64_t)st.epoch << 34;
-    if (n == 0) {  // nothing to do but to say so
+    if (n == 0) {  // nothing to do but to say so (no ticket is taken: the word stays 0)
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             if (total_out) *total_out = 0;
             if (total_out2) *total_out2 = 0;
         }
         return;
     }
-    int buf = 0;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {  // uniform per block
+    __shared__ uint32_t s_tile;
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(st.ticket, 1u);
+        if (t == gridDim.x - 1) atomicExch(st.ticket, 0u);  // every ticket of this launch has been taken
+        s_tile = t;
+    }
+    __syncthreads();
+    const int buf = 0;
+    const uint32_t tile = s_tile;
+    if (tile < ntiles) {   // uniform per block; nothing after the end is ever looked at
         const uint32_t base = tile * (uint32_t)kCpTile;
         uint64_t mask[kCpItems];  // wave-uniform
 #pragma unroll
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kCpThreads, 4) void k_compact(Pred pred, Emit emit,
                                __HIP_MEMORY_SCOPE_AGENT);
         // ---- look back.  The whole block does, one record per thread (tile-1-t): the blocks of a 1 M-point frame all
         // run at once, so inclusive prefixes are rare when the walk starts and a 64-wide window would need several
-        // dependent round trips through the fabric; 256 records per trip cover a 500 k-point span.
+        // dependent round trips through the fabric; 512 records per trip cover a 2 M-point span.
         uint32_t before = 0;
         if (tile > 0) {
             int32_t top = (int32_t)tile - 1;

@@ -15,6 +15,7 @@ constexpr int kWave = 64;
 // state of one chained-scan launch (gm_compact.hpp)
 struct ScanState {
     unsigned long long *status;  // [>= grid size] tile records
+    uint32_t *ticket;            // 0 between launches
     uint32_t epoch;              // 1 .. 2^30-1, different from the previous launches' on this array
 };
 

@@ -81,12 +81,13 @@ struct Slot {
     gm_frame_result last = {};
 };
 
-// record array + a fresh epoch for the next k_compact launch on this slot's stream
+// record array + ticket word + a fresh epoch for the next k_compact launch on this slot's stream
 inline ScanState next_scan(Slot &sl)
 {
     sl.scan_epoch = (sl.scan_epoch % 0x3FFFFFFEu) + 1u;  // 1 .. 2^30-2, never 0
     ScanState st;
     st.status = sl.blk;
+    st.ticket = reinterpret_cast<uint32_t *>(sl.blk + sl.blk_cap);
     st.epoch = sl.scan_epoch;
     return st;
 }

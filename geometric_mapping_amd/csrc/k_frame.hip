@@ -38,8 +38,8 @@ __device__ __forceinline__ void scatter_term(const float4 v /* nx,ny,nz,curvatur
 // block sum of m[6] in a fixed order -> row[0..6)
 __device__ __forceinline__ void scatter_row_store(const double m[6], double *__restrict__ row)
 {
-    __shared__ double red[256 / kWave][6];
-    const int w = threadIdx.x / kWave;
+    __shared__ double red[16][6];   // (blocks of up to 1024 threads)
+    const int w = threadIdx.x / kWave, nw = blockDim.x / kWave;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const double r = wave_sum(m[k]);
@@ -49,7 +49,7 @@ __device__ __forceinline__ void scatter_row_store(const double m[6], double *__r
     if (threadIdx.x < 6) {
         double r = 0;
 #pragma unroll
-        for (int j = 0; j < 256 / kWave; ++j) r += red[j][threadIdx.x];
+        for (int j = 0; j < nw; ++j) r += red[j][threadIdx.x];
         row[threadIdx.x] = r;
     }
 }

@@ -50,16 +50,16 @@ def test_chop_cloud_bit_exact(ctx, oc):
     assert 19 in rows and 20 not in rows and 17 not in rows and 18 not in rows
 
 
-@pytest.mark.parametrize("n", [1, 2047, 2048, 2049, 4096, 2048 * 257 + 5, 2048 * 1024 + 1, 2048 * 2500 + 77])
+@pytest.mark.parametrize("n", [1, 4095, 4096, 4097, 8192, 4096 * 513 + 5, 4096 * 1300 + 77])
 def test_chop_cloud_order_at_compaction_tile_boundaries(ctx, n):
-    """The crop is one launch of a chained scan over 2048-point tiles (csrc/gm_compact.hpp): sizes at and around tile
-    boundaries, more tiles than one look-back trip spans (256), and more tiles than the launch has blocks (1024: blocks
-    then take several tiles) must all give CropBox's order-preserving result -- checked against numpy, every row."""
+    """The crop is one launch of a chained scan over 4096-point tiles (csrc/gm_compact.hpp): sizes at and around tile
+    boundaries and more tiles than one look-back trip spans (512) must all give CropBox's order-preserving result --
+    checked against numpy, every row."""
     rng = np.random.default_rng(n)
     xyz = rng.uniform(-6.0, 6.0, size=(n, 3)).astype(np.float32)   # ~58 % inside the +-5 box
     if n > 100:
         xyz[rng.integers(0, n, 50)] = np.nan
-        xyz[: min(n, 3000)] = 9.0          # a run of whole tiles without a survivor
+        xyz[: min(n, 9000)] = 9.0          # a run of whole tiles without a survivor
     keep = np.flatnonzero(np.all(np.isfinite(xyz), axis=1) & np.all(np.abs(xyz) <= B, axis=1))
     out, rows = ctx.chopCloud(B, xyz)
     assert np.array_equal(rows, keep)
