@@ -341,13 +341,14 @@ def main():
         cloud_ptr = cloud_out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
         n_out = ctypes.c_uint32(0)
 
-        def per_frame(inputs, fetch_cloud=False):
+        def per_frame(inputs, fetch_cloud=False, c=None):
+            c = c or ctx
             ms = []
             for i in range(3 + args.frames):
                 t0 = time.perf_counter()
-                ctx.process_frame(inputs[i % len(inputs)])
+                c.process_frame(inputs[i % len(inputs)])
                 if fetch_cloud:                               # gm_get_cropped_xyz straight into the reused buffer
-                    st = ctx._L.gm_get_cropped_xyz(ctx._ctx, 0, cloud_ptr, n, ctypes.byref(n_out))
+                    st = c._L.gm_get_cropped_xyz(c._ctx, 0, cloud_ptr, n, ctypes.byref(n_out))
                     assert st == 0, st
                 if i >= 3:
                     ms.append((time.perf_counter() - t0) * 1e3)
@@ -365,6 +366,11 @@ def main():
             "host_rows_pinned_plus_choppedCloud_d2h": per_frame(pinned_inputs, fetch_cloud=True),
             "device_resident_rows": per_frame(clouds),
         }
+        # the same with the launch chain replayed from a captured hipGraph (GM_CFG_GRAPH)
+        gctx = make_ctx(flags | _lib.GM_CFG_GRAPH, 1)
+        secondary["per_frame"]["device_resident_rows_graph_replay"] = per_frame(clouds, c=gctx)
+        secondary["per_frame"]["host_rows_pinned_graph_replay"] = per_frame(pinned_inputs, c=gctx)
+        gctx.close()
         # rows handed over as HOST buffers with frames in flight (never the headline value)
         dt3, _ = timed(ctx, host_inputs, n_slots, min_warmup=4 * n_slots)
         secondary["host_input_pcie_inclusive"] = {"value": n * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3,

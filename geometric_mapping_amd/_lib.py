@@ -32,6 +32,7 @@ GM_CFG_RANSAC_PLANE = 1 << 2
 GM_CFG_RANSAC_CYLINDER = 1 << 3
 GM_CFG_STAGE_TIMING = 1 << 4
 GM_CFG_KEEP_COUNTS = 1 << 5
+GM_CFG_GRAPH = 1 << 6
 GM_CFG_DEFAULT = GM_CFG_VOXEL_GRID
 
 GM_CLOUD_DEVICE = 1 << 0

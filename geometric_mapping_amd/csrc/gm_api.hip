@@ -224,6 +224,7 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
     sl.sort.hist_cap = radix_hist_entries(cap);
     GM_HIP(ctx, dmalloc(sl.sort.hist, sl.sort.hist_cap));
     sl.cap = cap;
+    ++sl.alloc_gen;
     return GM_OK;
 }
 
@@ -283,9 +284,83 @@ static hipError_t upload_rows(Slot &sl, const gm_cloud *cloud, size_t raw_bytes,
     return hipSuccess;
 }
 
+// Launch sizes follow a bucketed point count (at most 1/16 above the frame's own): frames of about the same size then
+// share their launch geometry -- the condition for replaying a captured graph -- and kernels read the true counts from
+// device memory as they always did.
+static uint32_t size_bucket(uint32_t n)
+{
+    if (n == 0) return 0;
+    uint32_t p2 = 1024;
+    while (p2 < n && p2 < 0x80000000u) p2 <<= 1;
+    const uint32_t step = p2 / 16 < 1024u ? 1024u : p2 / 16;
+    const uint64_t b = ((uint64_t)n + step - 1) / step * step;
+    return b > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)b;
+}
+
+// Everything between the upload of the rows and the download of the result record: the launches of one frame.  With
+// sl.capturing set they go into a stream capture: no events, the point count comes from device memory (n_dev).
+static gm_status enqueue_launches(gm_ctx *ctx, Slot &sl, const RowLayout &rows, uint32_t n, uint32_t ns, const GridParams &g,
+                                  const VoxDense &vd, float lo, float hi)
+{
+    const gm_config &cf = ctx->cfg;
+    hipStream_t s = sl.stream;
+    const uint32_t *n_dev = nullptr;
+    if (sl.capturing) {
+        sl.scan_seq = 0;
+        // the frame's point count travels through a pinned word (the node's addresses are fixed, the value is not)
+        GM_HIP(ctx, hipMemcpyAsync(sl.frame_in, sl.h_frame_in, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        n_dev = sl.frame_in;
+    }
+    {
+        // one zero-fill launch opens the frame: device counters, dense voxel table, per-row table of the search
+        // grid, digit totals of the sort (all only touched later in this frame, on this stream)
+        ZeroJobs z;
+        memset(&z, 0, sizeof(z));
+        z.ptr[0] = sl.ctr; z.words8[0] = sizeof(DevCounters) / 8;
+        if (vd.enabled) { z.ptr[1] = sl.vox_table; z.words8[1] = (uint64_t)vd.dim * vd.dim * vd.dim * sizeof(VoxCell) / 8; }
+        if (sl.row_bounds) { z.ptr[2] = sl.row_bounds; z.words8[2] = (uint64_t)g.ny * (uint64_t)g.nz; }  // (no buffers yet
+        if (sl.sort.hist) { z.ptr[3] = sl.sort.hist; z.words8[3] = radix_totals_bytes() / 8; }           //  before the first non-empty frame)
+        z.frame_counter = sl.frame_in + 1;
+        launch_zero_fill(z, s);
+    }
+    launch_crop(rows, n, lo, hi, g, sl, s, ns, n_dev);
+    record(ctx, sl, 2);
+    launch_grid_and_normals(g, vd, sl, ns, (cf.flags & GM_CFG_KEEP_COUNTS) != 0, true, s);
+    record(ctx, sl, 3);  // end of grid+normals; the kernel alone is bracketed by ev_k0/ev_k1
+    // (getLocalFrame's scatter terms are summed by the compaction: one partial row per kCpTile cropped points)
+    const uint32_t nparts = launch_compact_valid(sl, ns, cf.weightingFactor, s);
+    record(ctx, sl, 4);
+    record(ctx, sl, 5);
+    sl.vox_sort_path = (cf.flags & GM_CFG_VOXEL_GRID) && !vd.enabled;
+    if (cf.flags & GM_CFG_VOXEL_GRID) {
+        if (vd.enabled) {
+            launch_voxel_dense_finalize(vd, sl, s);
+        } else {  // lattice too large for a table: min/max -> keys -> sort -> segmented mean
+            launch_minmax(sl.valid4, &sl.ctr->n_valid, ns, sl.ctr, s);
+            launch_voxel_grid(sl, ns, (float)cf.voxelGridLeafSize, voxel_key_bits(lo, hi, cf.voxelGridLeafSize), s);
+        }
+    }
+    record(ctx, sl, 6);
+    if (cf.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)) {
+        const gm_status st = gm_enqueue_ransac(ctx, sl, ns, nparts, kCpTile);   // its closing launch also finalizes the frame
+        if (st != GM_OK) return st;
+    }
+    if ((cf.flags & GM_CFG_NEAREST) && (cf.flags & GM_CFG_VOXEL_GRID)) {
+        const uint32_t nq_cap = vd.enabled ? (uint32_t)vd.dim * vd.dim * vd.dim : ns;
+        launch_nearest(sl.valid4, &sl.ctr->n_valid, ns, sl.vox4, &sl.ctr->n_voxels, nq_cap < ns ? nq_cap : ns, sl.nn_best,
+                       sl.vox_nn, s, sl.vnorm4, sl.vox_nrm4);
+    }
+    record(ctx, sl, 7);
+    if (!(cf.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)))
+        launch_frame_finalize(sl.tile_partials, nparts, kCpTile, sl, s);
+    GM_HIP(ctx, hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(FrameOut), hipMemcpyDeviceToHost, s));
+    return GM_OK;
+}
+
 gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool blocking_call)
 {
     const uint32_t n = cloud->n_points;
+    const uint32_t ns = size_bucket(n);
     const size_t raw_bytes = (size_t)n * cloud->point_step;
     const bool on_dev = (cloud->flags & GM_CLOUD_DEVICE) != 0;
     if (n && !cloud->data) return fail(ctx, GM_ERR_INVALID_ARG, "gm_cloud.data is NULL");
@@ -293,7 +368,7 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     if (st != GM_OK) return st;
     // n == 0 still sizes the buffers for one point: every stage below may then assume non-null scratch (an empty
     // cloud as the very first frame of a context used to reach the compaction with a null scratch array)
-    st = ensure_capacity(ctx, sl, n ? n : 1u, raw_bytes, !on_dev);
+    st = ensure_capacity(ctx, sl, ns ? ns : 1u, raw_bytes, !on_dev);
     if (st != GM_OK) return st;
     if (ctx->cfg.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER | GM_CFG_NEAREST)) {
         st = gm_ensure_ext(ctx, sl, ctx->cfg.ransac_hypotheses ? ctx->cfg.ransac_hypotheses : 1);
@@ -315,7 +390,7 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     // Eigen::Vector4f(-bound, ...) : double -> float (src/tunnel_processing.cpp:43-44)
     const float lo = (float)(-cf.boxFilterBound), hi = (float)cf.boxFilterBound;
     const float ext = hi - lo;
-    const GridParams g = make_grid(lo, lo, lo, ext, ext, ext, cf.neighborRadius, n);
+    const GridParams g = make_grid(lo, lo, lo, ext, ext, ext, cf.neighborRadius, ns);
     VoxDense vd;
     memset(&vd, 0, sizeof(vd));
     vd.own_lo = (float)ctx->own_lo;
@@ -330,52 +405,46 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
             sl.vox_table = nullptr;
             GM_HIP(ctx, dmalloc(sl.vox_table, cells));
             sl.vox_table_cap = cells;
+            ++sl.alloc_gen;
         }
     }
-    {
-        // one zero-fill launch opens the frame: device counters, dense voxel table, per-row table of the search
-        // grid, digit totals of the sort (all only touched later in this frame, on this stream)
-        ZeroJobs z;
-        memset(&z, 0, sizeof(z));
-        z.ptr[0] = sl.ctr; z.words8[0] = sizeof(DevCounters) / 8;
-        if (vd.enabled) { z.ptr[1] = sl.vox_table; z.words8[1] = (uint64_t)vd.dim * vd.dim * vd.dim * sizeof(VoxCell) / 8; }
-        if (sl.row_bounds) { z.ptr[2] = sl.row_bounds; z.words8[2] = (uint64_t)g.ny * (uint64_t)g.nz; }  // (no buffers yet
-        if (sl.sort.hist) { z.ptr[3] = sl.sort.hist; z.words8[3] = radix_totals_bytes() / 8; }           //  before the first non-empty frame)
-        launch_zero_fill(z, s);
-    }
-    launch_crop(rows, n, lo, hi, g, sl, s);
-    record(ctx, sl, 2);
-    launch_grid_and_normals(g, vd, sl, n, (cf.flags & GM_CFG_KEEP_COUNTS) != 0, true, s);
-    record(ctx, sl, 3);  // end of grid+normals; the kernel alone is bracketed by ev_k0/ev_k1
-    // (getLocalFrame's scatter terms are summed by the compaction: one partial row per kCpTile cropped points)
-    const uint32_t nparts = launch_compact_valid(sl, n, cf.weightingFactor, s);
-    record(ctx, sl, 4);
-    record(ctx, sl, 5);
-    sl.vox_sort_path = (cf.flags & GM_CFG_VOXEL_GRID) && !vd.enabled;
-    if (cf.flags & GM_CFG_VOXEL_GRID) {
-        if (vd.enabled) {
-            launch_voxel_dense_finalize(vd, sl, s);
-        } else {  // lattice too large for a table: min/max -> keys -> sort -> segmented mean
-            launch_minmax(sl.valid4, &sl.ctr->n_valid, n, sl.ctr, s);
-            launch_voxel_grid(sl, n, (float)cf.voxelGridLeafSize, voxel_key_bits(lo, hi, cf.voxelGridLeafSize), s);
-        }
-    }
-    record(ctx, sl, 6);
-    if (cf.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)) {
-        st = gm_enqueue_ransac(ctx, sl, n, nparts, kCpTile);   // its closing launch also finalizes the frame
+    // GM_CFG_GRAPH: the launch chain is captured once and replayed for every frame whose bucketed size, row layout,
+    // grid and buffers are those of the capture (all counts the kernels work with are device-resident; the one the host
+    // knows, the number of points, travels through a pinned word).  Not with stage timing (events between launches).
+    const bool graph = (cf.flags & GM_CFG_GRAPH) && !(cf.flags & GM_CFG_STAGE_TIMING) && n > 0;
+    if (!graph) {
+        st = enqueue_launches(ctx, sl, rows, n, ns, g, vd, lo, hi);
         if (st != GM_OK) return st;
+    } else {
+        unsigned char key[sizeof(sl.graph_key)];
+        uint32_t klen = 0;
+        auto put = [&](const void *p, size_t len) { memcpy(key + klen, p, len); klen += (uint32_t)len; };
+        static_assert(sizeof(RowLayout) + sizeof(GridParams) + sizeof(VoxDense) + 64 <= sizeof(sl.graph_key), "graph key");
+        memset(key, 0, sizeof(key));
+        put(&ns, 4); put(&sl.alloc_gen, 4); put(&rows, sizeof(rows)); put(&g, sizeof(g)); put(&vd, sizeof(vd));
+        put(&cf.flags, 4); put(&ctx->own_lo, 8); put(&ctx->own_hi, 8);
+        if (!sl.graph_exec || klen != sl.graph_key_len || memcmp(key, sl.graph_key, klen) != 0) {
+            if (sl.graph_exec) { hipGraphExecDestroy(sl.graph_exec); sl.graph_exec = nullptr; }
+            hipGraph_t graph_obj = nullptr;
+            GM_HIP(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            sl.capturing = true;
+            st = enqueue_launches(ctx, sl, rows, n, ns, g, vd, lo, hi);
+            sl.capturing = false;
+            const hipError_t ce = hipStreamEndCapture(s, &graph_obj);
+            if (st != GM_OK) { if (graph_obj) hipGraphDestroy(graph_obj); return st; }
+            GM_HIP(ctx, ce);
+            const hipError_t ie = hipGraphInstantiate(&sl.graph_exec, graph_obj, nullptr, nullptr, 0);
+            hipGraphDestroy(graph_obj);
+            GM_HIP(ctx, ie);
+            memcpy(sl.graph_key, key, sizeof(key));
+            sl.graph_key_len = klen;
+        }
+        sl.h_frame_in[0] = n;
+        GM_HIP(ctx, hipGraphLaunch(sl.graph_exec, s));
     }
-    if ((cf.flags & GM_CFG_NEAREST) && (cf.flags & GM_CFG_VOXEL_GRID)) {
-        const uint32_t nq_cap = vd.enabled ? (uint32_t)vd.dim * vd.dim * vd.dim : n;
-        launch_nearest(sl.valid4, &sl.ctr->n_valid, n, sl.vox4, &sl.ctr->n_voxels, nq_cap < n ? nq_cap : n, sl.nn_best,
-                       sl.vox_nn, s, sl.vnorm4, sl.vox_nrm4);
-    }
-    record(ctx, sl, 7);
-    if (!(cf.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)))
-        launch_frame_finalize(sl.tile_partials, nparts, kCpTile, sl, s);
-    GM_HIP(ctx, hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(FrameOut), hipMemcpyDeviceToHost, s));
     record(ctx, sl, 8);
     GM_HIP(ctx, hipGetLastError());
+    sl.kernel_timed = !graph;
     sl.submitted = true;
     sl.complete = false;
     return GM_OK;
@@ -403,7 +472,7 @@ void fill_result(gm_ctx *ctx, Slot &sl, gm_frame_result *r)
         for (int k = 0; k < 3; ++k) r->cylinder_axis_refit[k] = o.ext.cyl_axis_refit[k];
     }
     float ms = 0;
-    if (sl.n_in && hipEventElapsedTime(&ms, sl.ev_k0, sl.ev_k1) == hipSuccess) r->normals_kernel_ms = ms;
+    if (sl.n_in && sl.kernel_timed && hipEventElapsedTime(&ms, sl.ev_k0, sl.ev_k1) == hipSuccess) r->normals_kernel_ms = ms;
     if (ctx->cfg.flags & GM_CFG_STAGE_TIMING) {
         static const int stage_of[8] = {GM_STAGE_UPLOAD, GM_STAGE_CROP, GM_STAGE_NORMALS, GM_STAGE_COMPACT,
                                         GM_STAGE_FRAME, GM_STAGE_VOXEL, GM_STAGE_RANSAC, GM_STAGE_FRAME};
@@ -498,6 +567,7 @@ gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H)
     GM_HIP(ctx, hipMemset(sl.best_plane, 0xFF, 8));
     GM_HIP(ctx, hipMemset(sl.best_cyl, 0xFF, 8));
     sl.ext_H = HH; sl.ext_cap = sl.cap;
+    ++sl.alloc_gen;
     return GM_OK;
 }
 
@@ -660,6 +730,9 @@ gm_status gm_create(const gm_config *cfg, gm_ctx **out)
             GM_HIP(ctx, dmalloc(sl.voxp, 1));
             GM_HIP(ctx, dmalloc(sl.d_out, 1));
             GM_HIP(ctx, dmalloc(sl.partials, (size_t)kScatterBlocks * 6));
+            GM_HIP(ctx, dmalloc(sl.frame_in, 4));
+            GM_HIP(ctx, hipMemset(sl.frame_in, 0, 16));
+            GM_HIP(ctx, hipHostMalloc((void **)&sl.h_frame_in, 16, hipHostMallocDefault));
             GM_HIP(ctx, hipHostMalloc((void **)&sl.h_out, sizeof(FrameOut), hipHostMallocDefault));
             GM_HIP(ctx, hipMemset(sl.voxp, 0, sizeof(VoxelParams)));
             GM_HIP(ctx, hipMemset(sl.d_out, 0, sizeof(FrameOut)));
@@ -691,6 +764,9 @@ void gm_destroy(gm_ctx *ctx)
             if (sl.stream) hipStreamSynchronize(sl.stream);
             free_slot_buffers(sl);
             hipFree(sl.ctr); hipFree(sl.voxp); hipFree(sl.d_out); hipFree(sl.partials); hipFree(sl.vox_table);
+            hipFree(sl.frame_in);
+            if (sl.h_frame_in) hipHostFree(sl.h_frame_in);
+            if (sl.graph_exec) hipGraphExecDestroy(sl.graph_exec);
             hipFree(sl.hyp_plane); hipFree(sl.hyp_cyl); hipFree(sl.band); hipFree(sl.score_partial);
             hipFree(sl.cnt_plane); hipFree(sl.cnt_cyl); hipFree(sl.best_plane); hipFree(sl.best_cyl);
             hipFree(sl.mom_partial); hipFree(sl.mom_plane); hipFree(sl.mom_cyl); hipFree(sl.nn_best); hipFree(sl.vox_nrm4);

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(kCpThreads) void k_compact(Pred pred, Emit emit, co
     const uint32_t n = n_ptr ? *n_ptr : n_host;
     const uint32_t ntiles = (n + (uint32_t)kCpTile - 1u) / (uint32_t)kCpTile;
     const int w = threadIdx.x / kWave, lane = lane_id();
-    const uint64_t tag = (uint64_t)st.epoch << 34;
+    const uint32_t epoch = scan_epoch(st);
+    const uint64_t tag = (uint64_t)epoch << 34;
     if (n == 0) {  // nothing to do but to say so (no ticket is taken: the word stays 0)
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             if (total_out) *total_out = 0;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(kCpThreads) void k_compact(Pred pred, Emit emit, co
                 // (tiles "before tile 0" read as an inclusive prefix of 0: the walk always ends there at the latest)
                 const uint64_t sv = idx >= 0 ? __hip_atomic_load(&st.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                              : (tag | kInclusive);
-                const bool ready = (sv >> 34) == (uint64_t)st.epoch && ((sv >> 32) & 3u) != 0u;
+                const bool ready = (sv >> 34) == (uint64_t)epoch && ((sv >> 32) & 3u) != 0u;
                 const bool incl = ready && ((sv >> 32) & 3u) == 2u;
                 const uint64_t im = __ballot(incl), rm = __ballot(ready);
                 // per wave: lanes up to and including its first inclusive record (all lanes if it has none)

@@ -17,7 +17,17 @@ struct ScanState {
     unsigned long long *status;  // [>= grid size] tile records
     uint32_t *ticket;            // 0 between launches
     uint32_t epoch;              // 1 .. 2^30-1, different from the previous launches' on this array
+    const uint32_t *frame_ptr;   // graph replay (kernel arguments are frozen): epoch = f(*frame_ptr, epoch), see scan_epoch()
 };
+
+// Epoch of a chained-scan launch.  Launches enqueued one by one take it from the host (a per-slot counter, range
+// [1, 2^29)); launches replayed from a captured graph cannot -- their arguments are frozen -- and derive it from the
+// slot's device-side frame counter (bumped by the frame's opening kernel) and the launch's index in the frame, range
+// [2^29, 2^30): the two ranges never meet, so records of the one kind are never taken for records of the other.
+__device__ __forceinline__ uint32_t scan_epoch(const ScanState &st)
+{
+    return st.frame_ptr ? 0x20000000u + (((*st.frame_ptr) * 8u + st.epoch) & 0x1FFFFFFFu) : st.epoch;
+}
 
 struct DevCounters {
     uint32_t n_cropped;   // points surviving the crop box

@@ -50,6 +50,16 @@ struct Slot {
     unsigned long long *blk = nullptr;  // tile records of the single-pass compactions 
     uint32_t blk_cap = 0;
     uint32_t scan_epoch = 0;            // launches of k_compact on this slot so far (see gm_compact.hpp)
+    uint32_t scan_seq = 0;              // index of the next k_compact launch inside the frame being captured
+    // graph replay (GM_CFG_GRAPH): the frame's launch chain is captured once per (sizes, layout, configuration) and replayed
+    bool capturing = false;             // the launches being enqueued go into a stream capture
+    bool kernel_timed = false;          // ev_k0 / ev_k1 bracket the last frame's k_normals (not in a replayed frame)
+    uint32_t *frame_in = nullptr;       // device: [0] = points of the frame, [1] = frames replayed so far (epochs)
+    uint32_t *h_frame_in = nullptr;     // pinned: [0] = points of the frame (copied by a node of the graph)
+    hipGraphExec_t graph_exec = nullptr;
+    unsigned char graph_key[512] = {};  // everything the captured launches froze
+    uint32_t graph_key_len = 0;
+    uint32_t alloc_gen = 0;             // bumped whenever a device buffer of the slot is (re)allocated
     SortScratch sort = {};
     uint32_t *seg_start = nullptr;
     float4 *vox4 = nullptr;       // voxel centroids: x,y,z,count
@@ -84,11 +94,17 @@ struct Slot {
 // record array + ticket word + a fresh epoch for the next k_compact launch on this slot's stream
 inline ScanState next_scan(Slot &sl)
 {
-    sl.scan_epoch = (sl.scan_epoch % 0x3FFFFFFEu) + 1u;  // 1 .. 2^30-2, never 0
     ScanState st;
     st.status = sl.blk;
+    if (sl.capturing) {   // (replayed launches derive their epoch on the device)
+        st.epoch = sl.scan_seq++ & 7u;
+        st.frame_ptr = sl.frame_in + 1;
+    } else {
+        sl.scan_epoch = (sl.scan_epoch % 0x1FFFFFFEu) + 1u;  // 1 .. 2^29-2, never 0
+        st.epoch = sl.scan_epoch;
+        st.frame_ptr = nullptr;
+    }
     st.ticket = reinterpret_cast<uint32_t *>(sl.blk + sl.blk_cap);
-    st.epoch = sl.scan_epoch;
     return st;
 }
 
@@ -111,7 +127,8 @@ constexpr int kScatterBlocks = 1024;
 // ---- launchers (each enqueues on `s`, never synchronises) --------------------
 
 // k_crop.hip
-void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const GridParams &g, Slot &sl, hipStream_t s);
+void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const GridParams &g, Slot &sl, hipStream_t s,
+                 uint32_t n_size = 0, const uint32_t *n_dev = nullptr);
 // k_sort.hip : stable LSD radix sort of (key,val) pairs; n is device-resident.
 // Returns 0 if the sorted data ends in (keys_a, vals_a), 1 if in (keys_b, vals_b).
 size_t radix_totals_bytes();
@@ -123,7 +140,7 @@ uint32_t radix_hist_entries(uint32_t n_cap);
 void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, uint32_t n_cap, bool keep_counts,
                              bool scratch_cleared, hipStream_t s);
 // one launch that zero-fills up to four 8-byte-granular regions (the frame's counters and scratch tables)
-struct ZeroJobs { void *ptr[4]; uint64_t words8[4]; };
+struct ZeroJobs { void *ptr[4]; uint64_t words8[4]; uint32_t *frame_counter; };   // (+1 on the counter: one frame more)
 void launch_zero_fill(const ZeroJobs &jobs, hipStream_t s);
 uint32_t max_tiles(uint32_t n_cap, const GridParams &g);
 // k_frame.hip

@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256) void k_zero_fill(ZeroJobs jobs)
         const uint64_t nw = jobs.words8[j];
         for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (uint64_t)gridDim.x * blockDim.x) p[i] = z;
     }
+    // one frame more on this slot (the chained scans of a replayed graph take their epochs from this count)
+    if (jobs.frame_counter && blockIdx.x == 0 && threadIdx.x == 0) *jobs.frame_counter += 1u;
 }
 
 void launch_zero_fill(const ZeroJobs &jobs, hipStream_t s)
@@ -93,15 +95,18 @@ void launch_zero_fill(const ZeroJobs &jobs, hipStream_t s)
     hipLaunchKernelGGL(k_zero_fill, dim3(nb), dim3(256), 0, s, jobs);
 }
 
-void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const GridParams &g, Slot &sl, hipStream_t s)
+// n_size >= n sizes the launch; the point count is n, or *n_dev when given (a captured launch: its arguments are frozen)
+void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const GridParams &g, Slot &sl, hipStream_t s,
+                 uint32_t n_size, const uint32_t *n_dev)
 {
-    const uint32_t nb = compact_blocks(n);
+    if (n_size < n) n_size = n;
+    const uint32_t nb = compact_blocks(n_size);
     if (nb == 0) return;  // counters were zeroed: n_cropped stays 0
     RowReader rd{rows};
     CropPred pred{rd, lo, hi};
     CropEmit emit{rd, g, sl.crop4, sl.keys_a};
-    hipLaunchKernelGGL((k_compact<CropPred, CropEmit>), dim3(compact_grid(n)), dim3(kCpThreads), 0, s, pred, emit,
-                       (const uint32_t *)nullptr, n, next_scan(sl), &sl.ctr->n_cropped, (uint32_t *)nullptr);
+    hipLaunchKernelGGL((k_compact<CropPred, CropEmit>), dim3(compact_grid(n_size)), dim3(kCpThreads), 0, s, pred, emit,
+                       n_dev, n, next_scan(sl), &sl.ctr->n_cropped, (uint32_t *)nullptr);
 }
 
 }  // namespace gm

@@ -1491,7 +1491,7 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     // every tile; valu = the all-VALU kernel (A/B measurements, cross-checks in tests)
     static const char *impl = getenv("GM_NORMALS_IMPL");
     const uint32_t mx_min = !impl ? (uint32_t)kMxMinCandidates : (impl[0] == 'v' ? 0xFFFFFFFFu : (impl[0] == 'm' ? 0u : (uint32_t)kMxMinCandidates));
-    hipEventRecord(sl.ev_k0, s);
+    if (!sl.capturing) hipEventRecord(sl.ev_k0, s);
     // a trailing 0 (auto0 / mfma0) keeps the neighbour predicate on the VALU (k_normals_m: moments only on the matrix cores)
     const bool dist_on_mx = !(impl && strchr(impl, '0'));
     if (mx_min == 0xFFFFFFFFu) hipLaunchKernelGGL(k_normals_valu, dim3(nb), dim3(kNrThreads), 0, s, na);
@@ -1500,7 +1500,7 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
         else hipLaunchKernelGGL(k_normals<false>, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
     }
     else hipLaunchKernelGGL(k_normals_m, dim3(nb), dim3(kNrThreads), 0, s, na, mx_min);
-    hipEventRecord(sl.ev_k1, s);
+    if (!sl.capturing) hipEventRecord(sl.ev_k1, s);
 }
 
 }  // namespace gm

@@ -53,6 +53,9 @@ typedef enum gm_status {
 #define GM_CFG_RANSAC_CYLINDER (1u << 3) /* extension, no reference counterpart */
 #define GM_CFG_STAGE_TIMING    (1u << 4) /* bracket stages with hipEvents -> gm_frame_result.stage_ms */
 #define GM_CFG_KEEP_COUNTS     (1u << 5) /* keep per-point neighbour counts (tests) */
+#define GM_CFG_GRAPH           (1u << 6) /* capture the frame's launch chain as a hipGraph once and replay it for every
+                                            frame of about the same size (launch-bound small frames; results are the
+                                            same bit for bit; normals_kernel_ms / stage_ms are not measured) */
 #define GM_CFG_DEFAULT         (GM_CFG_VOXEL_GRID)
 
 /* The four numeric parameters are the reference's, with its types:

@@ -180,7 +180,8 @@ int main(int argc, char **argv)
         proc.reset(new gm_host::Processor(params->boxFilterBound, params->leafSize, params->neighborRadius,
                                           params->weightingFactor, 0,
                                           GM_CFG_DEFAULT | (params->rvizCylinder ? GM_CFG_RANSAC_CYLINDER : 0u) |
-                                              (params->rvizNormals ? GM_CFG_NEAREST : 0u)));
+                                              (params->rvizNormals ? GM_CFG_NEAREST : 0u) |
+                                              GM_CFG_GRAPH));   // one frame at a time: replay the launch chain
     } catch (const gm_host::Error &e) {
         ROS_FATAL("libgm_hip: %s", e.what());
         return 1;

@@ -539,3 +539,30 @@ def test_every_formulation_of_the_neighbourhood_kernel_finds_the_same_neighbours
         ok = np.isfinite(na[:, 0])
         assert np.quantile(ang(na[ok, :3], nb[ok, :3]), 0.999) < 1e-5
         assert np.abs(a[name + "_sc"] - b[name + "_sc"]).max() / np.abs(a[name + "_sc"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("ransac", [False, True])
+def test_graph_replay_is_bitwise_the_enqueued_frame(gm, ransac):
+    """GM_CFG_GRAPH: the frame's launch chain is captured once per bucket of frame sizes and replayed; frames of
+    different sizes inside one bucket (the count travels through device memory), of another bucket (re-capture), an
+    empty frame in between (enqueued directly) -- every result and every bulk output must equal the frame enqueued
+    launch by launch, bit for bit."""
+    from geometric_mapping_amd import _lib
+    fl = _lib.GM_CFG_DEFAULT | (_lib.GM_CFG_RANSAC_CYLINDER if ransac else 0)
+    sizes = [60000, 60000, 58111, 61440, 0, 200000, 57345, 60000]
+    frames = [synth.tunnel_frame(n, seed=11 + i) if n else np.zeros((0, 3), np.float32) for i, n in enumerate(sizes)]
+    keys = ("n_cropped", "n_valid", "n_voxels", "eigenvalues", "eigenvectors", "center_axis", "scatter6")
+    with gm.GeometricMapping(neighborRadius=0.4, flags=fl) as a, gm.GeometricMapping(neighborRadius=0.4, flags=fl | _lib.GM_CFG_GRAPH) as b:
+        for xyz in frames:
+            ra, rb = a.process_frame(xyz), b.process_frame(xyz)
+            for k in keys:
+                assert np.array_equal(np.asarray(ra[k]), np.asarray(rb[k]), equal_nan=True), k
+            if ransac:
+                assert np.array_equal(np.asarray(ra["cylinder"]), np.asarray(rb["cylinder"]), equal_nan=True)
+                assert ra["cylinder_inliers"] == rb["cylinder_inliers"]
+            if len(xyz):
+                assert np.array_equal(a.normals(), b.normals(), equal_nan=True)
+                (ca, ia), (cb, ib) = a.cropped_cloud(), b.cropped_cloud()
+                assert np.array_equal(ca, cb) and np.array_equal(ia, ib)
+                (va, na), (vb, nb) = a.voxel_centroids(), b.voxel_centroids()
+                assert np.array_equal(va, vb) and np.array_equal(na, nb)

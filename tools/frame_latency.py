@@ -8,7 +8,7 @@ from geometric_mapping_amd import _lib, synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=50)
-ap.add_argument("--flags", type=int, default=0)
+ap.add_argument("--flags", type=int, default=0, help="extra GM_CFG_* bits (8 = cylinder RANSAC, 64 = graph replay)")
 a = ap.parse_args()
 for n, r in ((50_000, 0.5), (100_000, None), (300_000, None), (1_000_000, None)):
     r = r or synth.fixed_k_radius(n)
