@@ -416,15 +416,22 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
         st = enqueue_launches(ctx, sl, rows, n, ns, g, vd, lo, hi);
         if (st != GM_OK) return st;
     } else {
-        unsigned char key[sizeof(sl.graph_key)];
+        unsigned char key[sizeof(sl.graph_key[0])];
         uint32_t klen = 0;
         auto put = [&](const void *p, size_t len) { memcpy(key + klen, p, len); klen += (uint32_t)len; };
-        static_assert(sizeof(RowLayout) + sizeof(GridParams) + sizeof(VoxDense) + 64 <= sizeof(sl.graph_key), "graph key");
+        static_assert(sizeof(RowLayout) + sizeof(GridParams) + sizeof(VoxDense) + 64 <= sizeof(sl.graph_key[0]), "graph key");
         memset(key, 0, sizeof(key));
         put(&ns, 4); put(&sl.alloc_gen, 4); put(&rows, sizeof(rows)); put(&g, sizeof(g)); put(&vd, sizeof(vd));
         put(&cf.flags, 4); put(&ctx->own_lo, 8); put(&ctx->own_hi, 8);
-        if (!sl.graph_exec || klen != sl.graph_key_len || memcmp(key, sl.graph_key, klen) != 0) {
-            if (sl.graph_exec) { hipGraphExecDestroy(sl.graph_exec); sl.graph_exec = nullptr; }
+        int gi = -1, victim = -1;   // victim: an empty entry if there is one, else the least recently used
+        for (int k = 0; k < Slot::kGraphs; ++k) {
+            if (sl.graph_exec[k] && sl.graph_key_len[k] == klen && memcmp(key, sl.graph_key[k], klen) == 0) gi = k;
+            if (victim >= 0 && !sl.graph_exec[victim]) continue;
+            if (victim < 0 || !sl.graph_exec[k] || sl.graph_used[k] < sl.graph_used[victim]) victim = k;
+        }
+        if (gi < 0) {
+            gi = victim;
+            if (sl.graph_exec[gi]) { hipGraphExecDestroy(sl.graph_exec[gi]); sl.graph_exec[gi] = nullptr; }
             hipGraph_t graph_obj = nullptr;
             GM_HIP(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             sl.capturing = true;
@@ -433,14 +440,15 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
             const hipError_t ce = hipStreamEndCapture(s, &graph_obj);
             if (st != GM_OK) { if (graph_obj) hipGraphDestroy(graph_obj); return st; }
             GM_HIP(ctx, ce);
-            const hipError_t ie = hipGraphInstantiate(&sl.graph_exec, graph_obj, nullptr, nullptr, 0);
+            const hipError_t ie = hipGraphInstantiate(&sl.graph_exec[gi], graph_obj, nullptr, nullptr, 0);
             hipGraphDestroy(graph_obj);
             GM_HIP(ctx, ie);
-            memcpy(sl.graph_key, key, sizeof(key));
-            sl.graph_key_len = klen;
+            memcpy(sl.graph_key[gi], key, sizeof(key));
+            sl.graph_key_len[gi] = klen;
         }
+        sl.graph_used[gi] = ++sl.graph_clock;
         sl.h_frame_in[0] = n;
-        GM_HIP(ctx, hipGraphLaunch(sl.graph_exec, s));
+        GM_HIP(ctx, hipGraphLaunch(sl.graph_exec[gi], s));
     }
     record(ctx, sl, 8);
     GM_HIP(ctx, hipGetLastError());
@@ -766,7 +774,7 @@ void gm_destroy(gm_ctx *ctx)
             hipFree(sl.ctr); hipFree(sl.voxp); hipFree(sl.d_out); hipFree(sl.partials); hipFree(sl.vox_table);
             hipFree(sl.frame_in);
             if (sl.h_frame_in) hipHostFree(sl.h_frame_in);
-            if (sl.graph_exec) hipGraphExecDestroy(sl.graph_exec);
+            for (int k = 0; k < Slot::kGraphs; ++k) if (sl.graph_exec[k]) hipGraphExecDestroy(sl.graph_exec[k]);
             hipFree(sl.hyp_plane); hipFree(sl.hyp_cyl); hipFree(sl.band); hipFree(sl.score_partial);
             hipFree(sl.cnt_plane); hipFree(sl.cnt_cyl); hipFree(sl.best_plane); hipFree(sl.best_cyl);
             hipFree(sl.mom_partial); hipFree(sl.mom_plane); hipFree(sl.mom_cyl); hipFree(sl.nn_best); hipFree(sl.vox_nrm4);

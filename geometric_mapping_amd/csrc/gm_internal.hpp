@@ -56,9 +56,12 @@ struct Slot {
     bool kernel_timed = false;          // ev_k0 / ev_k1 bracket the last frame's k_normals (not in a replayed frame)
     uint32_t *frame_in = nullptr;       // device: [0] = points of the frame, [1] = frames replayed so far (epochs)
     uint32_t *h_frame_in = nullptr;     // pinned: [0] = points of the frame (copied by a node of the graph)
-    hipGraphExec_t graph_exec = nullptr;
-    unsigned char graph_key[512] = {};  // everything the captured launches froze
-    uint32_t graph_key_len = 0;
+    static constexpr int kGraphs = 4;   // cached captures (a caller that rotates a few device buffers keeps them all)
+    hipGraphExec_t graph_exec[kGraphs] = {};
+    unsigned char graph_key[kGraphs][512] = {};  // everything the captured launches froze
+    uint32_t graph_key_len[kGraphs] = {};
+    uint64_t graph_used[kGraphs] = {};  // last use (least recently used is replaced)
+    uint64_t graph_clock = 0;
     uint32_t alloc_gen = 0;             // bumped whenever a device buffer of the slot is (re)allocated
     SortScratch sort = {};
     uint32_t *seg_start = nullptr;
