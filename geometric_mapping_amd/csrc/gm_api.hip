@@ -82,6 +82,7 @@ static int rows_per_radius(double radius, float ex, float ey, float ez, uint32_t
 GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, float ez, double radius, uint32_t n_points)
 {
     GridParams g;
+    memset(&g, 0, sizeof(g));   // (also the padding: the struct is compared bytewise as part of a graph key)
     float ext = fmaxf(ex, fmaxf(ey, ez));
     float hr = (float)radius * 1.001f;     // the radius-sized edge: x binning and the error band are relative to it
     if (!(hr > 1e-9f)) hr = 1e-9f;
@@ -243,6 +244,7 @@ gm_status make_rows(gm_ctx *ctx, const gm_cloud *c, const uint8_t *dev_data, Row
 {
     const gm_status lst = check_layout(ctx, c);
     if (lst != GM_OK) return lst;
+    memset(&rows, 0, sizeof(rows));   // (also the padding: compared bytewise as part of a graph key)
     rows.data = dev_data;
     rows.step = c->point_step; rows.ox = c->off_x; rows.oy = c->off_y; rows.oz = c->off_z;
     rows.bswap = (c->flags & GM_CLOUD_BIGENDIAN) ? 1u : 0u;
