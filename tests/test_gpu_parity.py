@@ -379,9 +379,12 @@ def test_process_frame_device_resident_rows(ctx, oc):
     assert np.array_equal(res["scatter6"], ref["scatter6"])
 
 
-def test_streaming_slots(gm, oc):
-    frames = [synth.tunnel_frame(20000, seed=s) for s in range(6)]
-    with gm.GeometricMapping(n_slots=2) as c:
+@pytest.mark.parametrize("graph", [False, True])
+def test_streaming_slots(gm, oc, graph):
+    """(graph: every slot replays its own captured launch chain, GM_CFG_GRAPH)"""
+    from geometric_mapping_amd import _lib
+    frames = [synth.tunnel_frame(20000 - 37 * s, seed=s) for s in range(6)]
+    with gm.GeometricMapping(n_slots=2, flags=_lib.GM_CFG_DEFAULT | (_lib.GM_CFG_GRAPH if graph else 0)) as c:
         single = [c.process_frame(f)["scatter6"] for f in frames]
         out = [None] * len(frames)
         c.submit_frame(0, frames[0])
