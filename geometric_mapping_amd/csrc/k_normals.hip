@@ -1414,16 +1414,18 @@ template <bool FINE>
 __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs A, uint32_t mx_min_candidates)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][(kMdWaveLdsBytes + 15) / 16 * 16];
+    uint32_t ntiles = A.ctr->n_tiles;
+    if (ntiles > A.tiles_cap) ntiles = A.tiles_cap;
+    const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
+    // (the grid is sized for the most tiles a frame of this size can have: most of its waves find no tile and leave here)
+    if (wave_id >= ntiles) return;
     // slots the staging never writes (past a chunk's end, the two pad rows) are read as MFMA operands whose products are
     // masked or land in unused result rows: they only have to be FINITE
     {
         uint4 *z = reinterpret_cast<uint4 *>(lds[threadIdx.x / kWave]);
         for (int i = lane_id(); i < kMdWaveLdsBytes / 16; i += kWave) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    uint32_t ntiles = A.ctr->n_tiles;
-    if (ntiles > A.tiles_cap) ntiles = A.tiles_cap;
-    const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
-    if (wave_id < ntiles) normals_tile_mxd<FINE>(A, lds[threadIdx.x / kWave], A.tiles[wave_id], mx_min_candidates);
+    normals_tile_mxd<FINE>(A, lds[threadIdx.x / kWave], A.tiles[wave_id], mx_min_candidates);
     if (ntiles > n_waves && wave_id != 0xFFFFFFFFu)
         for (uint32_t t = wave_id + n_waves; t < ntiles; t += n_waves)
             normals_tile_mxd<FINE>(A, lds[threadIdx.x / kWave], A.tiles[t], mx_min_candidates);
@@ -1467,8 +1469,17 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
                        (const float4 *)sl.crop4, (const uint32_t *)perm, (const uint32_t *)skeys, sl.ctr, (uint32_t)g.nx,
                        (uint32_t)(kTileSpan * (g.xreach - 1)), sl.spts4, sl.row_bounds, sl.tiles, sl.tiles_cap);
     // one wave per tile: four tiles per block
+    // A wave per tile for twice the tiles of a dense frame (n / 64: full 64-point tiles); a frame with more -- sparse rows
+    // cut into many short tiles, at most max_tiles() -- has the rest walked by the kernel's second, looped copy of the
+    // tile code.  (Sizing the grid for max_tiles() put 58 000 tile-less blocks behind the 7 400 working ones of the
+    // 1 M-point frame, each zeroing its LDS slice before finding out: 0.168 -> 0.165 ms for the kernel alone, 0.279 ->
+    // 0.269 ms per step with three frames in flight, once they leave first and most of them are not launched.)
     const uint32_t mt = max_tiles(n_cap, g);
     uint32_t nb = (mt + kNrWaves - 1) / kNrWaves;
+    {
+        const uint32_t usual = (n_cap / 32u + kNrWaves) / kNrWaves;
+        if (nb > usual) nb = usual < 64u ? 64u : usual;
+    }
     {
         // one wave per tile up to 65 536 blocks (262 144 tiles: a ~16 M-point frame), grid-stride beyond that.
         // GM_NORMALS_BLOCKS lowers the cap: tests use it to force the grid-stride path on a small frame.
