@@ -782,7 +782,7 @@ __device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned c
         bool thin;
         {
             uint32_t wl = (lane < 9 * kMxGroups && (lane % kMxGroups) == 0) ? se - sb : 0u;
-            wl = (uint32_t)wave_sum((unsigned long long)wl);
+            wl = wave_sum(wl);
             thin = wl < min_candidates;
         }
         // one origin per tile for the moment features: the tile's middle query (any point near the tile will do)
@@ -1092,7 +1092,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         bool thin = false;
         if (!FINE) {
             uint32_t wl = (lane < 9 * kMxGroups && (lane % kMxGroups) == 0) ? se - sb : 0u;
-            wl = (uint32_t)wave_sum((unsigned long long)wl);
+            wl = wave_sum(wl);
             thin = wl < min_candidates;
         }
         // one origin per tile: the tile's middle query snapped to a multiple of g.snap (a power of two >= one ulp of the
