@@ -424,12 +424,16 @@ __global__ __launch_bounds__(1024) void k_best_hypothesis(const int32_t *__restr
 }
 
 // ---- preemptive scoring (successive thirds): every stage costs about the same number of point-hypothesis tests ----
-//   stage 1: all H hypotheses on every 32nd point            -> the 256 best (count desc, hypothesis index asc)
-//   stage 2: those 256 on every 8th point                     -> the 32 best
-//   stage 3: those 32 on every point                          -> the winner (taken by the label kernel)
-// (H <= 256 starts at stage 2, H <= 32 is scored exhaustively.)
-constexpr int kPre1Stride = 32, kPre1Keep = 256;
-constexpr int kPre2Stride = 8, kPre2Keep = 32;
+//   stage 1: all H hypotheses on every 64th point            -> the 128 best (count desc, hypothesis index asc)
+//   stage 2: those 128 on every 16th point                    -> the 8 best
+//   stage 3: those 8 on every point                           -> the winner (taken by the label kernel)
+// (H <= 128 starts at stage 2, H <= 8 is scored exhaustively.)  H = 1024: 16 n + 8 n + 8 n point-hypothesis tests for a
+// frame of n points; the first version of the scheme (every 32nd / 8th point, 256 / 32 kept) spent 96 n -- a fifth of
+// the instructions of k_normals, which it shares the chip with when frames are in flight.  A sample of n / 64 points
+// (13 000 of the 1 M-point frame) ranks hypotheses whose inlier counts differ by a few per cent reliably; the kept sets
+// are deep enough (128, 8) that the eventual winner is not lost to sampling noise (tests/test_gpu_ext.py).
+constexpr int kPre1Stride = 64, kPre1Keep = 128;
+constexpr int kPre2Stride = 16, kPre2Keep = 8;
 // scratch layout (uint32 words): selA[256] cntA[256] selB[32] cntB[32]
 constexpr int kPreSelA = 0, kPreCntA = 256, kPreSelB = 512, kPreCntB = 544;  // 576 words, then
 constexpr int kPreDone = 576;  // the done-counter of select_by_last_block: zero between launches (gm_ensure_ext allocates 1024 zeroed words)
@@ -479,10 +483,14 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
     const uint32_t n_full = n_ptr ? *n_ptr : n_host;
     const uint32_t n = (n_full + stride - 1) / stride;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    // K <= 32 (the last stage): the wave's two halves score the SAME 32 hypotheses on different halves of the wave's
-    // points, so no lane idles in the most expensive stage; otherwise one hypothesis per lane, 64 per blockIdx.y
+    // K <= 32 (the last stage): the wave is cut into 64 / P parts (P = the power of two >= K) that score the SAME K
+    // hypotheses on different parts of the wave's points, so no lane idles in the stage that sees every point;
+    // otherwise one hypothesis per lane, 64 per blockIdx.y
     const bool split = K <= 32u;
-    const uint32_t slot = split ? (lane & 31u) : blockIdx.y * 64u + lane;  // which selected hypothesis this lane scores
+    uint32_t P = 64u;
+    if (split) { P = 1u; while (P < K) P <<= 1; }
+    const uint32_t parts = 64u / P;
+    const uint32_t slot = split ? (lane & (P - 1u)) : blockIdx.y * 64u + lane;  // which selected hypothesis this lane scores
     const uint32_t base = (blockIdx.x * 4u + wave) * PTS;
     const uint32_t m = base >= n ? 0u : ((n - base < (uint32_t)PTS) ? n - base : (uint32_t)PTS);
     const uint32_t groups = (m + 3u) >> 2;
@@ -511,8 +519,9 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
     }
     wave_lds_fence();  // every wave reads only the points it staged itself
     float c = 0.f;
-    // (every group of the wave's 64 is staged, points past the end as NaN, so a half-wave may read its 32 groups blind)
-    const uint32_t g0 = split ? (lane >> 5) * (PTS / 8) : 0u, g1 = split ? g0 + PTS / 8 : groups;
+    // (every group of the wave's 64 is staged, points past the end as NaN, so a part may read its groups blind)
+    const uint32_t gpp = (uint32_t)(PTS / 4) / parts;   // groups of four points per part
+    const uint32_t g0 = split ? (lane / P) * gpp : 0u, g1 = split ? g0 + gpp : groups;
     for (uint32_t gi = g0; gi < g1; ++gi) {
         const float4 X = lp[wave][gi][0], Y = lp[wave][gi][1], Z = lp[wave][gi][2];  // broadcast reads: 4 points
         const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
@@ -524,9 +533,10 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
     }
     red[wave][lane] = c;
     __syncthreads();
-    if (wave == 0 && slot < K && (!split || lane < 32u)) {
-        float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];  // exact: integers <= 1024
-        if (split) t += red[0][lane + 32] + red[1][lane + 32] + red[2][lane + 32] + red[3][lane + 32];
+    if (wave == 0 && slot < K && (!split || lane < P)) {
+        float t = 0.f;  // exact: integers <= 1024
+        for (uint32_t part = 0; part < (split ? parts : 1u); ++part)
+            t += red[0][lane + P * part] + red[1][lane + P * part] + red[2][lane + P * part] + red[3][lane + P * part];
         if (t > 0.f) atomicAdd(&counts_k[slot], (int32_t)t);
     }
     }

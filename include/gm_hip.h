@@ -227,10 +227,10 @@ gm_status gm_set_owned_range(gm_ctx *ctx, double own_lo, double own_hi);
  * these follow PCL's SampleConsensusModelPlane / SampleConsensusModelCylinder
  * conventions and are checked against oracle/gm_oracle_ext.c + analytic truth only.
  * With GM_CFG_RANSAC_PLANE / _CYLINDER a frame additionally runs, on its valid cloud:
- * seeded hypotheses -> batched scoring (preemptive, three stages of equal cost: all H
- * hypotheses on every 32nd point, the 256 best of them on every 8th point, the 32 best of
- * those on every point; order = count descending, hypothesis index ascending; H <= 256
- * starts at the second stage, H <= 32 is exhaustive) -> best model -> inlier labels (1 plane,
+ * seeded hypotheses -> batched scoring (preemptive, three stages: all H hypotheses on
+ * every 64th point, the 128 best of them on every 16th point, the 8 best of those on
+ * every point; order = count descending, hypothesis index ascending; H <= 128 starts at
+ * the second stage, H <= 8 is exhaustive) -> best model -> inlier labels (1 plane,
  * 2 cylinder; the cylinder samples and scores only points the plane left) ->
  * per-segment moments -> refits, reported in gm_frame_result. */
 

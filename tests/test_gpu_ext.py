@@ -102,11 +102,11 @@ def test_nearest(ctx, oc):
 
 def preemptive_best(score_fn, cloud, hyp, labels, want=0):
     """The in-frame RANSAC's staged scoring (csrc/k_ransac.hip launch_score_preemptive), restated with the oracle's
-    exhaustive scorer: all hypotheses on every 32nd point -> 256 best (count desc, index asc) -> those on every
-    8th point -> 32 best -> those on every point -> best full count (lowest index on ties).  H <= 256 starts at the
-    second stage, H <= 32 is exhaustive."""
+    exhaustive scorer: all hypotheses on every 64th point -> 128 best (count desc, index asc) -> those on every
+    16th point -> 8 best -> those on every point -> best full count (lowest index on ties).  H <= 128 starts at the
+    second stage, H <= 8 is exhaustive."""
     ids = np.arange(len(hyp))
-    for stride, keep in ((32, 256), (8, 32)):
+    for stride, keep in ((64, 128), (16, 8)):
         if len(ids) > keep:
             c = score_fn(cloud[::stride], hyp[ids], TAU, labels[::stride], want)
             ids = ids[np.lexsort((ids, -c))[:keep]]
