@@ -40,7 +40,11 @@ def make_cloud(rng, kind, n):
     raise ValueError(kind)
 
 
-CASES = list(range(28))
+import os
+
+# (GM_FUZZ_CASES=<n>: a longer one-off sweep, e.g. together with GM_NORMALS_ROWS=2|4 to drive the fine-row kernel or
+#  GM_FUZZ_FLAGS=64 to replay every frame from a captured graph)
+CASES = list(range(int(os.environ.get("GM_FUZZ_CASES", "28"))))
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -64,7 +68,7 @@ def test_random_frame_matches_oracle(gm, oc, case):
     step, offs = [(12, (0, 4, 8)), (16, (0, 4, 8)), (32, (8, 12, 16)), (22, (2, 6, 10))][case % 4]
     rows = synth.to_pointcloud2(xyz, point_step=step, offsets=offs, fill=0x5A)
     with gm.GeometricMapping(boxFilterBound=bound, voxelGridLeafSize=leaf, neighborRadius=radius, weightingFactor=wf,
-                             flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_KEEP_COUNTS) as c:
+                             flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_KEEP_COUNTS | int(os.environ.get("GM_FUZZ_FLAGS", "0"))) as c:
         res = c.process_frame(c.cloud_from_rows(rows, len(xyz), step, offs))
         cloud, crows = c.cropped_cloud()
         nrm = c.normals()
