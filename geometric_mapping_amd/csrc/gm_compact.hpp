@@ -28,6 +28,8 @@
 
 namespace gm {
 
+struct NoPayload {};   // predicates that load nothing worth keeping
+
 constexpr int kCpThreads = 512;
 constexpr int kCpItems = 8;
 constexpr int kCpTile = kCpThreads * kCpItems;  // points per tile
@@ -36,8 +38,9 @@ constexpr int kCpWaves = kCpThreads / kWave;
 inline uint32_t compact_blocks(uint32_t n) { return (n + kCpTile - 1) / kCpTile; }  // tiles of n points
 inline uint32_t compact_grid(uint32_t n) { return compact_blocks(n); }               // one block per tile
 
-// Pred: __device__ bool operator()(uint32_t i) const
-// Emit: __device__ void operator()(uint32_t src, uint32_t dst); static constexpr bool kHasFinish; when true,
+// Pred: typedef ... Payload (what the predicate has loaded and the emit step needs again: kept in registers, not re-read);
+//       __device__ bool operator()(uint32_t i, Payload &p) const
+// Emit: __device__ void operator()(uint32_t src, uint32_t dst, const Payload &p); static constexpr bool kHasFinish; when true,
 //       __device__ void finish(uint32_t tile) is called by every thread of the block once per tile that held input,
 //       after the tile's last emit (per-tile state lives in the functor; finish() resets it)
 // The element count is *n_ptr (device-resident) or n_host; the grid is compact_grid(capacity): a block per tile.  The number of survivors
@@ -75,10 +78,11 @@ __global__ __launch_bounds__(kCpThreads) void k_compact(Pred pred, Emit emit, co
     if (tile < ntiles) {   // uniform per block; nothing after the end is ever looked at
         const uint32_t base = tile * (uint32_t)kCpTile;
         uint64_t mask[kCpItems];  // wave-uniform
+        typename Pred::Payload pay[kCpItems];
 #pragma unroll
         for (int j = 0; j < kCpItems; ++j) {
             const uint32_t i = base + j * kCpThreads + threadIdx.x;
-            const bool v = (i < n) && pred(i);
+            const bool v = (i < n) && pred(i, pay[j]);
             mask[j] = __ballot(v);
             if (lane == 0) wcnt[buf][j][w] = (uint32_t)__popcll(mask[j]);
         }
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(kCpThreads) void k_compact(Pred pred, Emit emit, co
                 if (k < w) woff += c;
                 tot += c;
             }
-            if ((mask[j] >> lane) & 1ull) emit(i, running + woff + (uint32_t)__popcll(mask[j] & lanemask_lt()));
+            if ((mask[j] >> lane) & 1ull) emit(i, running + woff + (uint32_t)__popcll(mask[j] & lanemask_lt()), pay[j]);
             running += tot;
         }
         if constexpr (Emit::kHasFinish) emit.finish(tile);

@@ -48,12 +48,12 @@ struct RowReader {
 struct CropPred {
     RowReader rd;
     float lo, hi;
-    __device__ __forceinline__ bool operator()(uint32_t i) const
+    struct Payload { float x, y, z; };   // the row's coordinates: the emit step writes them, the rows are read once
+    __device__ __forceinline__ bool operator()(uint32_t i, Payload &p) const
     {
-        float x, y, z;
-        rd.load(i, x, y, z);
-        if (!finite3(x, y, z)) return false;
-        return !(x < lo || y < lo || z < lo || x > hi || y > hi || z > hi);
+        rd.load(i, p.x, p.y, p.z);
+        if (!finite3(p.x, p.y, p.z)) return false;
+        return !(p.x < lo || p.y < lo || p.z < lo || p.x > hi || p.y > hi || p.z > hi);
     }
 };
 
@@ -63,12 +63,10 @@ struct CropEmit {
     GridParams g;
     float4 *__restrict__ crop4;
     uint32_t *__restrict__ keys;
-    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst) const
+    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst, const CropPred::Payload &p) const
     {
-        float x, y, z;
-        rd.load(src, x, y, z);
-        crop4[dst] = make_float4(x, y, z, __uint_as_float(src));
-        keys[dst] = cell_key(g, x, y, z);
+        crop4[dst] = make_float4(p.x, p.y, p.z, __uint_as_float(src));
+        keys[dst] = cell_key(g, p.x, p.y, p.z);
     }
 };
 

@@ -20,7 +20,8 @@ namespace gm {
 // ---- compaction of points with a finite normal ----------------------------------
 struct ValidPred {
     const uint8_t *__restrict__ valid8;   // written by k_normals: finite normal && x in the rank's owned range
-    __device__ __forceinline__ bool operator()(uint32_t i) const { return valid8[i] != 0; }
+    typedef NoPayload Payload;
+    __device__ __forceinline__ bool operator()(uint32_t i, Payload &) const { return valid8[i] != 0; }
 };
 
 // one term of getLocalFrame's scatter matrix (src/tunnel_processing.cpp:100-124) added to m[6]
@@ -66,7 +67,7 @@ struct ValidEmit {
     double k_wf;                     // .001 / weightingFactor
     double *__restrict__ partials;   // [tiles][6]
     double m[6];
-    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst)
+    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst, const NoPayload &)
     {
         valid4[dst] = crop4[src];
         const float4 v = normals4[src];

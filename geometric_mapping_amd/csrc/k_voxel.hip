@@ -63,12 +63,13 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4 *__restrict__ p
 
 struct HeadPred {
     const uint32_t *__restrict__ skeys;
-    __device__ __forceinline__ bool operator()(uint32_t s) const { return s == 0 || skeys[s] != skeys[s - 1]; }
+    typedef NoPayload Payload;
+    __device__ __forceinline__ bool operator()(uint32_t s, Payload &) const { return s == 0 || skeys[s] != skeys[s - 1]; }
 };
 struct HeadEmit {
     static constexpr bool kHasFinish = false;
     uint32_t *__restrict__ seg_start;
-    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst) const { seg_start[dst] = src; }
+    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst, const NoPayload &) const { seg_start[dst] = src; }
 };
 
 __global__ __launch_bounds__(256) void k_voxel_centroids(const float4 *__restrict__ pts,
@@ -98,14 +99,15 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(const float4 *__restric
 // ---- dense-table fast path: ascending table order IS ascending pcl key order ----
 struct DensePred {
     const VoxCell *__restrict__ table;
-    __device__ __forceinline__ bool operator()(uint32_t i) const { return table[i].cnt != 0; }
+    typedef NoPayload Payload;
+    __device__ __forceinline__ bool operator()(uint32_t i, Payload &) const { return table[i].cnt != 0; }
 };
 struct DenseEmit {
     static constexpr bool kHasFinish = false;
     const VoxCell *__restrict__ table;
     float4 *__restrict__ vox4;
     double lo, inv_scale;
-    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst) const
+    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst, const NoPayload &) const
     {
         const VoxCell c = table[src];
         const double inv = inv_scale / (double)c.cnt;
