@@ -65,8 +65,10 @@ __device__ __forceinline__ v2f pk_within(v2f d2, v2f neg_big, v2f r2_big)
 }
 
 #ifndef GM_NRTHREADS
-#define GM_NRTHREADS 128   // two tiles per block: small blocks slot in beside the other frames' kernels (measured, 1 M frame,
-                           // three frames in flight: 64 / 128 / 256 / 512 threads = 0.332 / 0.326 / 0.374 / 0.40 ms per step)
+#define GM_NRTHREADS 256   // four tiles per block.  Measured on the 1 M frame with three frames in flight (tools/sweep_bench.sh),
+                           // this kernel as it stands at the end of round 2: 64 / 128 / 256 / 512 threads = 3.73 / 3.83 / 3.99 /
+                           // 3.89 G points/s (the kernel alone takes the same 0.165 ms with all but 512).  Its first matrix-core
+                           // version, with longer dependent chains per wave, wanted 128 (0.326 ms per step against 0.374).
 #endif
 constexpr int kNrThreads = GM_NRTHREADS;
 constexpr int kTileQ = kWave;             // queries per tile: one per lane
