@@ -23,7 +23,10 @@
 
 namespace gm {
 
-constexpr int kRsThreads = 512;   // 512-thread blocks slot in beside other frames' k_normals blocks sooner than 1024-thread ones: -2 % step time
+#ifndef GM_RSTHREADS
+#define GM_RSTHREADS 512
+#endif
+constexpr int kRsThreads = GM_RSTHREADS;   // 512-thread blocks slot in beside other frames' k_normals blocks sooner than 1024-thread ones: -2 % step time
 constexpr int kRsWaves = kRsThreads / kWave;  // 16
 constexpr int kRsMaxBits = 11;
 constexpr int kRsMaxPasses = 4;
