@@ -30,7 +30,10 @@ namespace gm {
 
 struct NoPayload {};   // predicates that load nothing worth keeping
 
-constexpr int kCpThreads = 512;
+#ifndef GM_CPTHREADS
+#define GM_CPTHREADS 512
+#endif
+constexpr int kCpThreads = GM_CPTHREADS;
 constexpr int kCpItems = 8;
 constexpr int kCpTile = kCpThreads * kCpItems;  // points per tile
 constexpr int kCpWaves = kCpThreads / kWave;

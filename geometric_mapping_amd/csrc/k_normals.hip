@@ -99,7 +99,10 @@ constexpr int kNrWaves = kNrThreads / kWave;
 // (kTbSpan positions per step) -- no table written by another block is read, so nothing has to precede this launch.
 // A thread owns kTbPer CONSECUTIVE positions (one 16 B key load): the block's chain of barrier-separated steps
 // (~10 us of latency) is paid once per 4096 positions and a 1 M-point frame is one round of resident blocks.
-constexpr int kTbThreads = 1024;
+#ifndef GM_TBTHREADS
+#define GM_TBTHREADS 1024
+#endif
+constexpr int kTbThreads = GM_TBTHREADS;
 constexpr int kTbPer = 4;
 constexpr int kTbSpan = kTbThreads * kTbPer;
 __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const float4 *__restrict__ crop4,
