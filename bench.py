@@ -424,6 +424,14 @@ def main():
                     "peak_wave_instr_per_s_packed": 1024 * 2.4e9 / 4.0,
                     "mfma_busy_frac_pmc": vj["derived"].get("mfma_busy_frac"),
                     "source": os.path.relpath(vprof, ROOT)}
+            # the matrix-core side of the same kernel: v_mfma_f32_32x32x16_bf16 = 2 * 32 * 32 * 16 flops per wave instruction
+            mf = vj["counters"].get("SQ_INSTS_MFMA")
+            if mf and k_roof:
+                tf = float(mf) * 32768.0 / (k_roof * 1e-3) / 1e12
+                valu["mfma"] = {"SQ_INSTS_MFMA_per_launch": float(mf), "achieved_TFLOPs_bf16": tf, "peak_TFLOPs_bf16_dense": 2500.0,
+                                "frac": tf / 2500.0,
+                                "note": "exact bf16 splits (3 terms per fp32 value) and 0/1 weights: flops of the formulation, "
+                                        "not of an fp32 GEMM; the kernel is bound by the VALU work that feeds the products"}
         except Exception:
             valu = None
 
