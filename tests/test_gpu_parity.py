@@ -544,14 +544,16 @@ def test_every_formulation_of_the_neighbourhood_kernel_finds_the_same_neighbours
         assert np.abs(a[name + "_sc"] - b[name + "_sc"]).max() / np.abs(a[name + "_sc"]).max() < 1e-6
 
 
-@pytest.mark.parametrize("ransac", [False, True])
+@pytest.mark.parametrize("ransac", [False, True, "nearest"])
 def test_graph_replay_is_bitwise_the_enqueued_frame(gm, ransac):
     """GM_CFG_GRAPH: the frame's launch chain is captured once per bucket of frame sizes and replayed; frames of
     different sizes inside one bucket (the count travels through device memory), of another bucket (re-capture), an
     empty frame in between (enqueued directly) -- every result and every bulk output must equal the frame enqueued
     launch by launch, bit for bit."""
     from geometric_mapping_amd import _lib
-    fl = _lib.GM_CFG_DEFAULT | (_lib.GM_CFG_RANSAC_CYLINDER if ransac else 0)
+    nearest = ransac == "nearest"   # (the node's configuration with displayNormals: 1-NN + gathered normals in the frame)
+    ransac = ransac is True
+    fl = _lib.GM_CFG_DEFAULT | (_lib.GM_CFG_RANSAC_CYLINDER if ransac else 0) | (_lib.GM_CFG_NEAREST if nearest else 0)
     sizes = [60000, 60000, 58111, 61440, 0, 200000, 57345, 60000]
     frames = [synth.tunnel_frame(n, seed=11 + i) if n else np.zeros((0, 3), np.float32) for i, n in enumerate(sizes)]
     keys = ("n_cropped", "n_valid", "n_voxels", "eigenvalues", "eigenvectors", "center_axis", "scatter6")
@@ -569,3 +571,5 @@ def test_graph_replay_is_bitwise_the_enqueued_frame(gm, ransac):
                 assert np.array_equal(ca, cb) and np.array_equal(ia, ib)
                 (va, na), (vb, nb) = a.voxel_centroids(), b.voxel_centroids()
                 assert np.array_equal(va, vb) and np.array_equal(na, nb)
+                if nearest:
+                    assert np.array_equal(a.voxel_normals(), b.voxel_normals(), equal_nan=True)
