@@ -44,11 +44,11 @@ void free_slot_buffers(Slot &sl)
     hipFree(sl.d_raw); hipFree(sl.crop4); hipFree(sl.keys_a); hipFree(sl.keys_b); hipFree(sl.vals_a);
     hipFree(sl.vals_b); hipFree(sl.spts4); hipFree(sl.normals4); hipFree(sl.counts); hipFree(sl.valid4);
     hipFree(sl.vnorm4); hipFree(sl.tiles); hipFree(sl.row_bounds); hipFree(sl.blk); hipFree(sl.tile_partials); hipFree(sl.sort.hist); hipFree(sl.seg_start);
-    hipFree(sl.vox4); hipFree(sl.vox_nn); hipFree(sl.labels); hipFree(sl.valid8);
+    hipFree(sl.vox4); hipFree(sl.vox_nn); hipFree(sl.labels);
     if (sl.h_raw) hipHostFree(sl.h_raw);
     sl.d_raw = nullptr; sl.h_raw = nullptr; sl.crop4 = nullptr; sl.keys_a = sl.keys_b = sl.vals_a = sl.vals_b = nullptr;
     sl.spts4 = sl.normals4 = sl.valid4 = sl.vnorm4 = sl.vox4 = nullptr; sl.counts = nullptr; sl.tiles = nullptr; sl.row_bounds = nullptr;
-    sl.blk = nullptr; sl.tile_partials = nullptr; sl.sort.hist = nullptr; sl.seg_start = nullptr; sl.vox_nn = nullptr; sl.labels = nullptr; sl.valid8 = nullptr;
+    sl.blk = nullptr; sl.tile_partials = nullptr; sl.sort.hist = nullptr; sl.seg_start = nullptr; sl.vox_nn = nullptr; sl.labels = nullptr;
     sl.cap = 0; sl.raw_cap = 0; sl.tiles_cap = 0;
 }
 
@@ -213,7 +213,7 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
     GM_HIP(ctx, dmalloc(sl.counts, cap));
     GM_HIP(ctx, dmalloc(sl.valid4, cap)); GM_HIP(ctx, dmalloc(sl.vnorm4, cap));
     GM_HIP(ctx, dmalloc(sl.seg_start, cap)); GM_HIP(ctx, dmalloc(sl.vox4, cap));
-    GM_HIP(ctx, dmalloc(sl.vox_nn, cap)); GM_HIP(ctx, dmalloc(sl.labels, cap)); GM_HIP(ctx, dmalloc(sl.valid8, cap));
+    GM_HIP(ctx, dmalloc(sl.vox_nn, cap)); GM_HIP(ctx, dmalloc(sl.labels, cap));
     sl.tiles_cap = cap + 2u;  // every tile holds >= 1 point
     GM_HIP(ctx, dmalloc(sl.tiles, sl.tiles_cap));
     GM_HIP(ctx, dmalloc(sl.row_bounds, (size_t)1024 * 1024));  // make_grid caps every axis at 1024 cells

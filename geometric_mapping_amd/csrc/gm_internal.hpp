@@ -41,7 +41,6 @@ struct Slot {
     uint32_t *skeys = nullptr; // == whichever of keys_a/keys_b holds the sorted keys
     float4 *normals4 = nullptr;   // per cropped point: nx,ny,nz,curvature (NaN when <3 neighbours)
     int32_t *counts = nullptr;    // per cropped point neighbour count (GM_CFG_KEEP_COUNTS)
-    uint8_t *valid8 = nullptr;    // per cropped point: kept by the NaN-normal compaction (written by k_normals)
     float4 *valid4 = nullptr;     // compacted cloud (finite normals)
     float4 *vnorm4 = nullptr;     // compacted normals
     uint2 *tiles = nullptr;

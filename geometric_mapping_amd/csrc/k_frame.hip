@@ -18,10 +18,16 @@
 namespace gm {
 
 // ---- compaction of points with a finite normal ----------------------------------
+// removeNaNNormalsFromPointCloud's predicate: all three components finite.  (k_normals stores no normal for a point the
+// rank does not own, so slab ownership needs no test of its own.)  The normal rides to the emit step in registers.
 struct ValidPred {
-    const uint8_t *__restrict__ valid8;   // written by k_normals: finite normal && x in the rank's owned range
-    typedef NoPayload Payload;
-    __device__ __forceinline__ bool operator()(uint32_t i, Payload &) const { return valid8[i] != 0; }
+    const float4 *__restrict__ normals4;
+    typedef float4 Payload;
+    __device__ __forceinline__ bool operator()(uint32_t i, Payload &p) const
+    {
+        p = normals4[i];
+        return finite3(p.x, p.y, p.z);
+    }
 };
 
 // one term of getLocalFrame's scatter matrix (src/tunnel_processing.cpp:100-124) added to m[6]
@@ -60,17 +66,15 @@ __device__ __forceinline__ void scatter_row_store(const double m[6], double *__r
 // tile), so getLocalFrame needs no pass of its own over the compacted normals.
 struct ValidEmit {
     static constexpr bool kHasFinish = true;
-    const float4 *__restrict__ normals4;
     const float4 *__restrict__ crop4;
     float4 *__restrict__ valid4;
     float4 *__restrict__ vnorm4;
     double k_wf;                     // .001 / weightingFactor
     double *__restrict__ partials;   // [tiles][6]
     double m[6];
-    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst, const NoPayload &)
+    __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst, const float4 &v)
     {
         valid4[dst] = crop4[src];
-        const float4 v = normals4[src];
         vnorm4[dst] = v;
         scatter_term(v, k_wf, m);
     }
@@ -131,8 +135,8 @@ uint32_t launch_compact_valid(Slot &sl, uint32_t n_cap, double wf, hipStream_t s
 {
     const uint32_t nb = compact_blocks(n_cap);
     if (nb == 0) return 0;
-    ValidPred pred{sl.valid8};   // (the rank's owned range was applied by k_normals when it wrote the flags)
-    ValidEmit emit{sl.normals4, sl.crop4, sl.valid4, sl.vnorm4, .001 / wf, sl.tile_partials, {0, 0, 0, 0, 0, 0}};
+    ValidPred pred{sl.normals4};
+    ValidEmit emit{sl.crop4, sl.valid4, sl.vnorm4, .001 / wf, sl.tile_partials, {0, 0, 0, 0, 0, 0}};
     hipLaunchKernelGGL((k_compact<ValidPred, ValidEmit>), dim3(compact_grid(n_cap)), dim3(kCpThreads), 0, s, pred, emit,
                        (const uint32_t *)&sl.ctr->n_cropped, 0u, next_scan(sl), &sl.ctr->n_valid, &sl.ctr->vox_n);
     return nb;  // partial rows: one per tile that held input (the finalizer derives how many from n_cropped)

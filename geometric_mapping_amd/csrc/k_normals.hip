@@ -331,7 +331,7 @@ __device__ __forceinline__ bool smallest_eigpair(const double c[6], double &lam,
 // Returns whether the point enters the voxel grid (finite normal and owned by this rank's slab).
 __device__ __forceinline__ bool emit_normal(bool active, const float4 q, const double mom[10], const VoxDense &vd,
                                             float4 *__restrict__ normals4, int32_t *__restrict__ counts, uint32_t qn,
-                                            unsigned long long stat_t0, uint8_t *__restrict__ valid8)
+                                            unsigned long long stat_t0)
 {
     bool vox_ok = false;
     const int cnt = (int)mom[0];
@@ -354,8 +354,10 @@ __device__ __forceinline__ bool emit_normal(bool active, const float4 q, const d
                 vox_ok = finite3(out.x, out.y, out.z) && q.x >= vd.own_lo && q.x < vd.own_hi;
             }
         }
+        // The NaN-normal compaction keeps a point iff its stored normal is finite: a point this rank does not own (halo of a
+        // slab: a neighbour, never an output) is therefore stored without one -- no separate validity array to scatter into.
+        if (!vox_ok) out = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
         normals4[dst] = out;
-        valid8[dst] = vox_ok ? 1u : 0u;   // removeNaNNormalsFromPointCloud's predicate (+ slab ownership): the compaction reads 1 B per point
         if (counts) counts[dst] = cnt;
 #ifdef GM_NORMALS_TIMELINE  // diagnostic build (tools/tile_timeline.py): lanes 0 / 1 of a tile report its end tick / duration
         {
@@ -419,7 +421,6 @@ struct NormalsArgs {
     int32_t *__restrict__ counts;
     VoxDense vd;
     VoxCell *__restrict__ vox_table;
-    uint8_t *__restrict__ valid8;   // per cropped point: 1 = finite normal and owned by this rank (what the NaN compaction keeps)
 };
 
 // ---- one tile, all-VALU formulation ------------------------------------------------
@@ -469,7 +470,6 @@ __device__ __forceinline__ void normals_tile_valu(const NormalsArgs &A, unsigned
             if (active) {
                 const float nanv = __builtin_nanf("");
                 normals4[__float_as_uint(q.w)] = make_float4(nanv, nanv, nanv, nanv);
-                A.valid8[__float_as_uint(q.w)] = 0u;
                 if (counts) counts[__float_as_uint(q.w)] = 0;
             }
             return;
@@ -651,9 +651,9 @@ __device__ __forceinline__ void normals_tile_valu(const NormalsArgs &A, unsigned
                      Sxy = T[5 * kWave], Sxz = T[6 * kWave], Syy = T[7 * kWave], Syz = T[8 * kWave], Szz = T[9 * kWave];
         const double mom[10] = {Sn, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz};
 #ifdef GM_NORMALS_TIMELINE
-        const bool vox_ok = emit_normal(active, q, mom, vd, normals4, counts, qn, stat_t0, A.valid8);
+        const bool vox_ok = emit_normal(active, q, mom, vd, normals4, counts, qn, stat_t0);
 #else
-        const bool vox_ok = emit_normal(active, q, mom, vd, normals4, counts, qn, 0ull, A.valid8);
+        const bool vox_ok = emit_normal(active, q, mom, vd, normals4, counts, qn, 0ull);
 #endif
         if (vd.enabled) voxel_sums(vox_ok, q, vd, vox_table);
     }
@@ -750,7 +750,6 @@ __device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned c
             if (active) {
                 const float nanv = __builtin_nanf("");
                 normals4[__float_as_uint(q.w)] = make_float4(nanv, nanv, nanv, nanv);
-                A.valid8[__float_as_uint(q.w)] = 0u;
                 if (counts) counts[__float_as_uint(q.w)] = 0;
             }
             return;
@@ -837,7 +836,7 @@ __device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned c
                     }
                 }
             }
-            const bool vox_ok = emit_normal(active, q, tm, vd, normals4, counts, qn, stat_t0, A.valid8);
+            const bool vox_ok = emit_normal(active, q, tm, vd, normals4, counts, qn, stat_t0);
             if (vd.enabled) voxel_sums(vox_ok, q, vd, vox_table);
             return;
         }
@@ -955,7 +954,7 @@ __device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned c
 #pragma unroll
         for (int m = 0; m < 9; ++m) mom[1 + m] = (frow(1 + 3 * m) + frow(2 + 3 * m)) + frow(3 + 3 * m);
 
-        const bool vox_ok = emit_normal(active, q, mom, vd, normals4, counts, qn, stat_t0, A.valid8);
+        const bool vox_ok = emit_normal(active, q, mom, vd, normals4, counts, qn, stat_t0);
         if (vd.enabled) voxel_sums(vox_ok, q, vd, vox_table);
     }
 }
@@ -1051,7 +1050,6 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             if (active) {
                 const float nanv = __builtin_nanf("");
                 normals4[__float_as_uint(q.w)] = make_float4(nanv, nanv, nanv, nanv);
-                A.valid8[__float_as_uint(q.w)] = 0u;
                 if (counts) counts[__float_as_uint(q.w)] = 0;
             }
             return;
@@ -1182,7 +1180,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                     }
                 }
             }
-            const bool vox_ok = emit_normal(active, q, tm, vd, normals4, counts, qn, stat_t0, A.valid8);
+            const bool vox_ok = emit_normal(active, q, tm, vd, normals4, counts, qn, stat_t0);
             if (vd.enabled) voxel_sums(vox_ok, q, vd, vox_table);
             return;
         }
@@ -1368,7 +1366,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         uint32_t qidx_e = qs + (active ? (uint32_t)lane : qn - 1u);
         asm volatile("" : "+v"(qidx_e));
         const float4 qe = spts4[qidx_e];
-        const bool vox_ok = emit_normal(active, qe, mom, vd, normals4, counts, qn, stat_t0, A.valid8);
+        const bool vox_ok = emit_normal(active, qe, mom, vd, normals4, counts, qn, stat_t0);
         if (vd.enabled) voxel_sums(vox_ok, qe, vd, vox_table);
     }
 }
@@ -1501,7 +1499,7 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     NormalsArgs na;
     na.spts4 = sl.spts4; na.skeys = skeys; na.tiles = sl.tiles; na.ctr = sl.ctr; na.g = g; na.tiles_cap = sl.tiles_cap;
     na.row_bounds = sl.row_bounds; na.normals4 = sl.normals4; na.counts = keep_counts ? sl.counts : (int32_t *)nullptr;
-    na.vd = vdx; na.vox_table = sl.vox_table; na.valid8 = sl.valid8;
+    na.vd = vdx; na.vox_table = sl.vox_table;
     // GM_NORMALS_IMPL: auto (default) = moments on the matrix cores except for thin neighbourhoods (fewer than
     // kMxMinCandidates candidates in a tile's windows), which take the kernel's direct fp64 path; mfma = matrix cores for
     // every tile; valu = the all-VALU kernel (A/B measurements, cross-checks in tests)

@@ -24,7 +24,7 @@ rows = {
     # round 2, second half: the compactions are single launches (chained scan); the NaN-normal removal also sums the
     # scatter-matrix terms of the survivors (getLocalFrame needs no pass of its own: its 16 B per point are not read again)
     "gm::k_compact<gm::CropPred, gm::CropEmit>": ("fromROSMsg + CropBox (order-preserving), one launch", 12 * n_in + 12 * n_c, 16 * n_in + 16 * n_c + 4 * n_c),
-    "gm::k_compact<gm::ValidPred, gm::ValidEmit>": ("removeNaNNormals + ExtractIndices + getLocalFrame partial sums, one launch", 28 * n_c + 28 * n_v, n_c + 32 * n_v + 32 * n_v),
+    "gm::k_compact<gm::ValidPred, gm::ValidEmit>": ("removeNaNNormals + ExtractIndices + getLocalFrame partial sums, one launch", 28 * n_c + 28 * n_v, 16 * n_c + 16 * n_v + 32 * n_v),
     "gm::k_compact_count<gm::CropPred>": ("CropBox predicate pass", 12 * n_in, 12 * n_in),
     "gm::k_compact_scatter<gm::CropPred, gm::CropEmit>": ("CropBox copy (order-preserving)", 12 * n_in + 12 * n_c, 12 * n_in + 16 * n_c + 4 * n_c),
     # since round 2 the predicate is a 1-byte flag per point written by k_normals (the 12 B of the normal it stands for are
