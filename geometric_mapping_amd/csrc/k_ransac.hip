@@ -888,7 +888,10 @@ uint32_t launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t wa
     uint32_t nb = (n_cap + 255) / 256;
     if (nb > 2048) nb = 2048;
     if (mom_partial) {   // one partial row per block: ~4096 points per block, at most kScatterBlocks rows
-        nb = (n_cap + 4095) / 4096;
+#ifndef GM_LABEL_PTS
+#define GM_LABEL_PTS 4096
+#endif
+        nb = (n_cap + GM_LABEL_PTS - 1) / GM_LABEL_PTS;
         if (nb < 64u) nb = (n_cap + 255) / 256 < 64u ? (n_cap + 255) / 256 : 64u;
         if (nb > (uint32_t)kScatterBlocks) nb = kScatterBlocks;
     }
