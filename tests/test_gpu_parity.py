@@ -498,7 +498,7 @@ def test_frame_smaller_than_capacity_with_another_sort_layout(gm):
     assert np.array_equal(nrm, ref_n, equal_nan=True)
 
 
-@pytest.mark.parametrize("impl", ["valu", "mfma", "auto0", "mfma0", "rows2", "rows4"])
+@pytest.mark.parametrize("impl", ["valu", "mfma", "auto0", "mfma0", "rows2", "rows4", "sortstaged"])
 def test_every_formulation_of_the_neighbourhood_kernel_finds_the_same_neighbours(impl):
     """GM_NORMALS_IMPL (read once per process -> child processes): the all-VALU kernel, the production kernel (distances
     and moments on the matrix cores, exact re-evaluation inside a band) forced onto every tile, and the variant that
@@ -526,7 +526,10 @@ def test_every_formulation_of_the_neighbourhood_kernel_finds_the_same_neighbours
             env = dict(os.environ)
             env.pop("GM_NORMALS_IMPL", None)
             env.pop("GM_NORMALS_ROWS", None)
-            if tag and tag.startswith("rows"):
+            env.pop("GM_SORT_STAGED", None)
+            if tag == "sortstaged":     # the LDS-staged radix scatter (chosen for frames beyond ~1 M points) on small frames
+                env["GM_SORT_STAGED"] = "1"
+            elif tag and tag.startswith("rows"):
                 env["GM_NORMALS_ROWS"] = tag[4:]
             elif tag:
                 env["GM_NORMALS_IMPL"] = tag
