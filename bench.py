@@ -66,6 +66,7 @@ def parse():
                     help="nccl (= RCCL) is the real thing; gloo only rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this device")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--graph", type=int, default=0, help="1: the timed contexts replay their launch chains from captured hipGraphs (GM_CFG_GRAPH)")
     ap.add_argument("--frames", type=int, default=24, help="frames of the per-frame (blocking, H2D-inclusive) protocol")
     ap.add_argument("--profile-tag", default=None, help="rNN prefix of the profiles/ files to quote (default: newest)")
     return ap.parse_args()
@@ -190,6 +191,8 @@ def main():
     radius = args.radius if args.radius else synth.fixed_k_radius(n)
     bound, leaf, wf = 5.0, 0.5, 0.2
     flags = _lib.GM_CFG_DEFAULT   # no per-stage events inside the timed region; a separate short run reads them
+    if args.graph:
+        flags |= _lib.GM_CFG_GRAPH
     ransac_on = False
     if args.ransac:
         probe = g.load_library()
