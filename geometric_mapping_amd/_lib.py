@@ -13,6 +13,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgm_hip.so")
+if os.environ.get("GM_LIB_PATH"):   # experiments only (tools/build_variants.sh): another build of the same library
+    LIB_PATH = os.environ["GM_LIB_PATH"]
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gm_hip.h")
 
 GM_OK = 0

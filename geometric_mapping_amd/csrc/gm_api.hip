@@ -221,7 +221,11 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
     GM_HIP(ctx, dmalloc(sl.tile_partials, (size_t)compact_blocks(cap) * 6));
     GM_HIP(ctx, dmalloc(sl.blk, (size_t)sl.blk_cap + 1));  // + the ticket word
     GM_HIP(ctx, hipMemsetAsync(sl.blk, 0, sizeof(unsigned long long) * ((size_t)sl.blk_cap + 1), sl.stream));
-    sl.scan_epoch = 0;
+    {
+        // tests only: start the chained scans' epoch counter just below its wrap (tests/test_gpu_parity.py)
+        static const char *e = getenv("GM_TEST_SCAN_EPOCH");
+        sl.scan_epoch = e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
+    }
     sl.sort.hist_cap = radix_hist_entries(cap);
     GM_HIP(ctx, dmalloc(sl.sort.hist, sl.sort.hist_cap));
     sl.cap = cap;
@@ -378,6 +382,11 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     }
     hipStream_t s = sl.stream;
     sl.n_in = n;
+    // Epochs of replayed (graph) scans are (frame counter * 8 + launch index) mod 2^29: they repeat every 2^26 frames of
+    // the slot.  Twice per period the records are cleared between two frames (all of them are stale there), so that a
+    // record can never be as old as a period.
+    if ((++sl.frames_enqueued & 0x1FFFFFFu) == 0u && sl.blk)
+        GM_HIP(ctx, hipMemsetAsync(sl.blk, 0, sizeof(unsigned long long) * (size_t)sl.blk_cap, s));
     record(ctx, sl, 0);
     const uint8_t *dev_rows = (const uint8_t *)cloud->data;
     if (!on_dev && n) {
@@ -742,6 +751,11 @@ gm_status gm_create(const gm_config *cfg, gm_ctx **out)
             GM_HIP(ctx, dmalloc(sl.partials, (size_t)kScatterBlocks * 6));
             GM_HIP(ctx, dmalloc(sl.frame_in, 4));
             GM_HIP(ctx, hipMemset(sl.frame_in, 0, 16));
+            if (const char *e = getenv("GM_TEST_FRAME_COUNTER")) {   // tests only: start near the replayed epochs' wrap
+                const uint32_t v = (uint32_t)strtoul(e, nullptr, 0);
+                GM_HIP(ctx, hipMemcpy(sl.frame_in + 1, &v, 4, hipMemcpyHostToDevice));
+                sl.frames_enqueued = v;
+            }
             GM_HIP(ctx, hipHostMalloc((void **)&sl.h_frame_in, 16, hipHostMallocDefault));
             GM_HIP(ctx, hipHostMalloc((void **)&sl.h_out, sizeof(FrameOut), hipHostMallocDefault));
             GM_HIP(ctx, hipMemset(sl.voxp, 0, sizeof(VoxelParams)));

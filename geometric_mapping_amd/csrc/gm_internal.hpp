@@ -50,6 +50,7 @@ struct Slot {
     uint32_t blk_cap = 0;
     uint32_t scan_epoch = 0;            // launches of k_compact on this slot so far (see gm_compact.hpp)
     uint32_t scan_seq = 0;              // index of the next k_compact launch inside the frame being captured
+    uint32_t frames_enqueued = 0;       // host mirror of the device-side frame counter (frame_in[1]) that replayed scans take their epochs from
     // graph replay (GM_CFG_GRAPH): the frame's launch chain is captured once per (sizes, layout, configuration) and replayed
     bool capturing = false;             // the launches being enqueued go into a stream capture
     bool kernel_timed = false;          // ev_k0 / ev_k1 bracket the last frame's k_normals (not in a replayed frame)
@@ -102,7 +103,14 @@ inline ScanState next_scan(Slot &sl)
         st.epoch = sl.scan_seq++ & 7u;
         st.frame_ptr = sl.frame_in + 1;
     } else {
-        sl.scan_epoch = (sl.scan_epoch % 0x1FFFFFFEu) + 1u;  // 1 .. 2^29-2, never 0
+        // 1 .. 2^29-2, never 0.  When the counter wraps, the records are cleared (on the slot's stream, behind every
+        // launch that wrote them): a record left at a tile index that no launch of the last 2^29 has reached would
+        // otherwise carry the epoch that is about to be reused and read as ready.
+        if (sl.scan_epoch >= 0x1FFFFFFEu) {
+            (void)hipMemsetAsync(sl.blk, 0, sizeof(unsigned long long) * (size_t)sl.blk_cap, sl.stream);
+            sl.scan_epoch = 0;
+        }
+        sl.scan_epoch += 1u;
         st.epoch = sl.scan_epoch;
         st.frame_ptr = nullptr;
     }

@@ -9,24 +9,34 @@
 // fewer than 3 neighbours.
 //
 // MI355X design (not a kd-tree walk):
-//  * points are binned into a uniform grid (cell edge >= r) by a stable radix
-//    sort of cell keys, x fastest, so the 3x3x3 neighbourhood of a run of cells
-//    in one x-row is 9 CONTIGUOUS ranges of the sorted array;
-//  * a work item ("tile") is <= 64 consecutive sorted points of one x-row: one
-//    query per lane, the tile's candidates are streamed through a 4 KiB
-//    wave-private SoA LDS window (coalesced 16 B/lane loads in, broadcast
-//    ds_read_b128 out: four candidates' x, y or z per read), so no block
-//    barrier exists in the hot loop; the wave's four 16-lane groups walk
-//    their own x-windows of a row in lock-step;
-//  * each lane keeps 10 fp32 accumulators of offsets FROM ITS OWN QUERY POINT
-//    (|offset| < r: no cancellation), folded into fp64 once per 64 candidates;
-//  * the 3x3 solve runs in fp64 (MI355X fp64 vector rate is half the fp32 rate;
-//    ~250 instructions against ~15 000 in the neighbour loop);
-//  * one wave per tile, blocks retire after their tile: the hardware block
-//    scheduler balances the uneven candidate counts and lets other frames'
-//    kernels interleave.
-// Bound: fp32 VALU issue (~21 ops per query-candidate pair), not HBM: every
-// candidate byte is read once per tile and reused by 64 lanes.
+//  * points are binned into a uniform grid (y/z cell edge >= r, or r/D for frames with very many
+//    neighbours per point; x binned 64x finer) by a stable radix sort of cell keys, x fastest, so the
+//    neighbourhood of a run of cells in one x-row is (2D+1)^2 CONTIGUOUS, x-sorted ranges of the
+//    sorted array (k_rows_and_tiles publishes every row's range and cuts the work items);
+//  * a work item ("tile") is <= 64 consecutive sorted points of one x-row, one wave per tile, no
+//    block barrier anywhere: the wave finds the tile's candidate windows (all 64 lanes probing one
+//    range at a time: two rounds of loads per search), then streams them in chunks of 128
+//    candidates through a private 10 KB LDS slice, the rows of the next chunk in flight in
+//    registers while the current one is worked on;
+//  * a chunk is staged as a feature-major bf16 image: every fp32 monomial {1, u, u u^T, |u|^2} of
+//    the candidate's offset u from a tile origin cut exactly into three bf16 terms.  One image
+//    feeds BOTH matrix products of the pair loop (v_mfma_f32_32x32x16_bf16): the squared distances
+//    |u|^2 + |v|^2 - 2 u.v of 32 candidates x 32 queries (through gfx950's transposed LDS read),
+//    turned into exact 0/1 weights by one clamped bf16 conversion -- pairs closer to the threshold
+//    than the product's error bound are re-evaluated with FLANN's own fp32 chain, so the neighbour
+//    sets are bit-exact -- and the ten moments sum_c G[f][c] W[c][q], whose weight operand is the
+//    first product's result as it stands in the registers;
+//  * thin neighbourhoods (sparse clouds) skip the image: offsets from the query itself, fp64 sums;
+//  * the 3x3 solve runs in fp64 per query (closed-form root + two Newton steps, eigenvector =
+//    largest cross product as pcl::eigen33 picks it); the epilogue also adds the point to the dense
+//    voxel table (exact fixed-point sums: pcl::VoxelGrid, src/tunnel_processing.cpp:217-220);
+//  * blocks retire after their four tiles: the hardware block scheduler balances the uneven
+//    candidate counts and lets other frames' kernels interleave; consecutive runs of blocks are
+//    dealt to one XCD so that a sorted row is fetched into one L2.
+// Bound: instruction issue and the latency of a wave's own dependent steps (VALU staging + MFMA
+// pair loop), not HBM: every candidate byte is read once per tile and reused by 64 queries
+// (DESIGN.md par. 4 has the measured breakdown).  k_normals_valu / k_normals_m are the earlier
+// all-VALU / moments-only formulations, kept for A/B measurements and cross-checks in tests.
 #include <stdlib.h>
 #include <string.h>
 
@@ -1004,6 +1014,18 @@ __device__ __forceinline__ s4 md_tr_read(const unsigned char *p)
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)p);
 }
 
+#ifndef GM_NORMALS_PREFETCH
+#define GM_NORMALS_PREFETCH 1   // 0: a chunk's rows are loaded when the chunk is staged (A/B measurements)
+#endif
+#ifdef GM_NORMALS_PHASES   // diagnostic build (tools/normals_phases.py): shader-clock ticks a wave spends in each part of a tile
+__device__ unsigned long long gm_phase_ticks[16];
+#define GM_PH_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define GM_PH_ADD(slot, expr) do { ph_acc[slot] += (uint32_t)(expr); } while (0)
+#else
+#define GM_PH_STAMP(var) do {} while (0)
+#define GM_PH_ADD(slot, expr) do {} while (0)
+#endif
+
 // FINE = false: the usual grid (cells one radius wide, 3 x 3 rows: everything about rows is a compile-time constant);
 // FINE = true: y/z rows finer than the radius (GridParams::D > 1), chosen for frames with very many neighbours per point.
 template <bool FINE>
@@ -1020,17 +1042,22 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
     VoxCell *__restrict__ vox_table = A.vox_table;
     (void)ctr;
     uint32_t *feat = reinterpret_cast<uint32_t *>(lds);    // this wave's slice: feature rows only
-    const int lane = lane_id();
+    // (the lane id goes through an empty asm: each inlined copy of this function then derives its lane patterns from a value
+    // of its own, and the compiler cannot keep one copy's patterns alive in registers across the other copy's loops)
+    int lane = lane_id();
+    asm volatile("" : "+v"(lane));
     const uint32_t n = ctr->n_cropped;
     const int qsel = lane & 31, half = lane >> 5;
     // lane roles of the transposed reads that build the distance MFMA's A fragment (see the header of this section)
     const int tq = (lane & 15) >> 2, tp = lane & 3, tr0 = 16 * ((lane >> 4) & 1);
-    uint32_t rowoff[2][2];
+    uint32_t rowoff[2][2];   // byte offset of this lane's transposed reads inside a 32-candidate block: feature row + candidate quad
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) rowoff[t][e] = md_row_of_slot(16 * t + 8 * half + 4 * e + tq) * 16u;
-    const uint32_t tr_lane_off = (uint32_t)((tr0 + 4 * tp) >> 3) * (uint32_t)(kMdOctetWords * 4) + (uint32_t)((tr0 + 4 * tp) & 7) * 2u;
+        for (int e = 0; e < 2; ++e)
+            rowoff[t][e] = md_row_of_slot(16 * t + 8 * half + 4 * e + tq) * 16u +
+                           (uint32_t)((tr0 + 4 * tp) >> 3) * (uint32_t)(kMdOctetWords * 4) + (uint32_t)((tr0 + 4 * tp) & 7) * 2u;
+    const uint32_t mom_off = (uint32_t)qsel * 16u + 8u * (uint32_t)half;   // ... and of its moment-MFMA operand reads
     {
         const uint32_t qs = tile.x, qn = tile.y;
 #ifdef GM_NORMALS_TIMELINE
@@ -1038,6 +1065,10 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
 #else
         const unsigned long long stat_t0 = 0ull;
 #endif
+#ifdef GM_NORMALS_PHASES
+        uint32_t ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (wave-uniform: scalar registers)
+#endif
+        GM_PH_STAMP(ph_t0);
         const bool active = (uint32_t)lane < qn;
         const uint32_t qidx = qs + (active ? (uint32_t)lane : qn - 1u);
         const float4 q = spts4[qidx];
@@ -1070,32 +1101,40 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             const int a = (r % side) - gD, b = (r / side) - gD;
             const int yy = cy + a, zz = cz + b;
             const int reach = (lane >> 1) < nrows ? (FINE ? (int)g.reach[a < 0 ? -a : a][b < 0 ? -b : b] : g.xreach) : 0;
+            uint32_t key_b = 0, key_e = 0, lo1 = 0, hi1 = 0;
             if (reach > 0 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
                 const uint32_t nrow = (uint32_t)(zz * g.ny + yy);
                 const uint2 rb = row_bounds[nrow];
                 const uint32_t rbk = nrow * (uint32_t)g.nx;
                 const int xa = lo_fx > reach ? lo_fx - reach : 0;
                 const int xb = hi_fx + reach < g.nx - 1 ? hi_fx + reach : g.nx - 1;
-                const uint32_t key_b = rbk + (uint32_t)xa, key_e = rbk + (uint32_t)xb + 1u;
-                uint32_t lo1 = rb.x, hi1 = rb.y, lo2 = rb.x, hi2 = rb.y;
-                while (lo1 < hi1 || lo2 < hi2) {
-                    const uint32_t m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
-                    const uint32_t k1 = skeys[m1 < n ? m1 : n - 1u], k2 = skeys[m2 < n ? m2 : n - 1u];
-                    if (lo1 < hi1) { if (k1 < key_b) lo1 = m1 + 1u; else hi1 = m1; }
-                    if (lo2 < hi2) { if (k2 < key_e) lo2 = m2 + 1u; else hi2 = m2; }
-                }
-                sb = lo1; se = lo2;
+                key_b = rbk + (uint32_t)xa; key_e = rbk + (uint32_t)xb + 1u;
+                lo1 = rb.x; hi1 = rb.y;
             }
+            uint32_t lo2 = lo1, hi2 = hi1;
+            while (lo1 < hi1 || lo2 < hi2) {
+                const uint32_t m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
+                const uint32_t k1 = skeys[m1 < n ? m1 : n - 1u], k2 = skeys[m2 < n ? m2 : n - 1u];
+                if (lo1 < hi1) { if (k1 < key_b) lo1 = m1 + 1u; else hi1 = m1; }
+                if (lo2 < hi2) { if (k2 < key_e) lo2 = m2 + 1u; else hi2 = m2; }
+            }
+            sb = lo1; se = lo2;
         };
         find_windows(0);
+        GM_PH_STAMP(ph_t1);
+        GM_PH_ADD(0, ph_t1 - ph_t0);   // tile head: query + key loads, window search
         // Thin neighbourhoods (fewer than min_candidates candidates in the first group's windows) take the direct path
         // below: nothing to amortise the feature staging over, and the few-point covariances of a sparse cloud are
         // near-degenerate, where offsets from the query itself (|offset| < r) in fp64 keep more than offsets from a
         // tile origin through bf16 features do.  (Only on the usual grid: finer rows are chosen for dense frames.)
         bool thin = false;
         if (!FINE) {
-            uint32_t wl = (lane < 9 * kMxGroups && (lane % kMxGroups) == 0) ? se - sb : 0u;
-            wl = wave_sum(wl);
+            // (summed on the scalar side: a wave_sum here would leave its six shuffle patterns in vector registers all the
+            // way to the epilogue's reductions, across the candidate stream)
+            uint32_t wl = 0;
+#pragma unroll
+            for (int r = 0; r < 9; ++r)
+                wl += __builtin_amdgcn_readlane(se, r * kMxGroups) - __builtin_amdgcn_readlane(sb, r * kMxGroups);
             thin = wl < min_candidates;
         }
         // one origin per tile: the tile's middle query snapped to a multiple of g.snap (a power of two >= one ulp of the
@@ -1184,21 +1223,43 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             if (vd.enabled) voxel_sums(vox_ok, q, vd, vox_table);
             return;
         }
+        GM_PH_STAMP(ph_t2);
+        GM_PH_ADD(1, ph_t2 - ph_t1);   // origin, query-side operand fragments
+        // ---- the candidate stream.  A chunk's rows are fetched one chunk AHEAD: the loads of chunk i+1 are issued right
+        // after chunk i has been staged and stay in flight, in six registers, while the wave runs chunk i's pair loops --
+        // a wave owns its LDS slice, nothing else can hide that round trip (it used to be paid twice per chunk, once per
+        // candidate of the lane's pair, with the wave idle: a quarter of a tile's lifetime).  Lane l takes candidates
+        // 2l and 2l+1 of the chunk (two bf16 of a feature row make one dword); a lane past the end re-reads the chunk's
+        // last row, so every lane's loads are unconditional.
+        static_assert(kMdChunk == 2 * kWave, "one candidate pair per lane and chunk");
+        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+        auto fetch_chunk = [&](uint32_t c0, uint32_t clen) {
+            const uint32_t i = 2u * (uint32_t)lane, last = clen - 1u;
+            pa = spts4[c0 + (i < last ? i : last)];
+            pb = spts4[c0 + (i + 1u < last ? i + 1u : last)];
+        };
         for (int row0 = 0;;) {
         seek(0, row_begin(0));
+        if (nlen) fetch_chunk(nc0, nlen);
         while (nlen) {
             const int r = nr;
             const uint32_t c0 = nc0, clen = nlen;
             wave_lds_fence();  // previous chunk fully consumed
-            // ---- stage the chunk: each lane takes candidate PAIRS (two bf16 of a feature row make one dword)
-#pragma unroll
-            for (int k = 0; k < (kMdChunk + 2 * kWave - 1) / (2 * kWave); ++k) {
-                const uint32_t i = 2u * (uint32_t)lane + (uint32_t)k * 2u * kWave;
+            GM_PH_STAMP(ph_c0);
+#if !GM_NORMALS_PREFETCH
+            fetch_chunk(c0, clen);
+#endif
+#ifdef GM_NORMALS_PHASES
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GM_PH_STAMP(ph_c1);
+            GM_PH_ADD(2, ph_c1 - ph_c0);   // waiting for the chunk's rows
+#endif
+            // ---- stage the chunk
+            {
+                const uint32_t i = 2u * (uint32_t)lane;
                 if (i < clen) {
                     const bool vb = i + 1u < clen;
-                    const float4 ca = spts4[c0 + i];
-                    float4 cb = ca;
-                    if (vb) cb = spts4[c0 + i + 1u];
+                    const float4 ca = pa, cb = pb;
                     const float uxa = ca.x - ox, uya = ca.y - oy, uza = ca.z - oz;
                     const float uxb = vb ? cb.x - ox : 0.f, uyb = vb ? cb.y - oy : 0.f, uzb = vb ? cb.z - oz : 0.f;
                     const uint32_t oct = i >> 3;
@@ -1231,6 +1292,13 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             }
             wave_lds_fence();
             if (c0 + clen < row_end(r)) seek(r, c0 + clen); else seek(r + 1, r + 1 < nrows ? row_begin(r + 1) : 0u);
+#if GM_NORMALS_PREFETCH
+            if (nlen) fetch_chunk(nc0, nlen);   // in flight during the pair loops below
+#endif
+            GM_PH_STAMP(ph_c2);
+#ifdef GM_NORMALS_PHASES
+            GM_PH_ADD(3, ph_c2 - ph_c1);   // feature image of the chunk
+#endif
 #pragma unroll
             for (int gi = 0; gi < kMxGroups; ++gi) {
                 if (gi >= ngroups) break;  // wave-uniform
@@ -1256,12 +1324,12 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                     const unsigned char *blk = fbytes + (p >> 3) * (uint32_t)(kMdOctetWords * 4);
                     // ---- distance MFMA: D1[candidate p + r][query] over the 24 k-slots.  A fragment (candidate rows,
                     // feature k) out of the feature-major image by transposed reads: 4 rows x 16 candidates per read
-                    const unsigned char *ta = blk + tr_lane_off;
+                    const unsigned char *ta = blk;
                     union { bf16x8 v; s4 h[2]; } a0, a1;
                     a0.h[0] = md_tr_read(ta + rowoff[0][0]); a0.h[1] = md_tr_read(ta + rowoff[0][1]);
                     a1.h[0] = md_tr_read(ta + rowoff[1][0]); a1.h[1] = md_tr_read(ta + rowoff[1][1]);
                     // moment MFMA's A fragments (feature row qsel, the two quads of k-step s of this lane half)
-                    const unsigned char *ma = blk + (uint32_t)qsel * 16u + 8u * (uint32_t)half;
+                    const unsigned char *ma = blk + mom_off;
                     union { bf16x8 v; uint2 q2[2]; } m0, m1;
                     m0.q2[0] = *reinterpret_cast<const uint2 *>(ma);
                     m0.q2[1] = *reinterpret_cast<const uint2 *>(ma + kMdOctetWords * 4);
@@ -1311,6 +1379,12 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                     }
 #endif
                     if (__ballot(amin < g.dband)) {   // rare: some pair of this block lies inside the band
+                        // (the lane's query of this group is read again, an L2 hit, rather than kept in three registers per
+                        // group across the whole stream: those registers hold the next chunk's rows)
+                        uint32_t gqi = (uint32_t)(gi * kMxGroupLanes + qsel);
+                        gqi = qs + (gqi < qn ? gqi : qn - 1u);
+                        asm volatile("" : "+v"(gqi));   // (keeps the address arithmetic here, out of the loop's live registers)
+                        const float4 gqv = spts4[gqi];
 #pragma unroll
                         for (int k = 0; k < 16; ++k) {
                             const uint32_t rk = (uint32_t)((k & 3) + 8 * (k >> 2) + 4 * half);
@@ -1318,10 +1392,10 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                             if (__ballot(need)) {
                                 if (need) {
                                     const float4 c = spts4[c0 + p + rk];
-                                    const float dx = c.x - gq[gi][0], dy = c.y - gq[gi][1], dz = c.z - gq[gi][2];
+                                    const float dx = c.x - gqv.x, dy = c.y - gqv.y, dz = c.z - gqv.z;
                                     // FLANN L2_Simple: every product and sum rounded, in this order; strict d2 < r2
                                     const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-                                    const uint32_t wk = d2 < g.r2 ? 0x3F80u : 0u;
+                                    const uint32_t wk = (d2 < g.r2 ? 1u : 0u) * 0x3F80u;   // (a multiply: no constant held in a register across the loop)
                                     pw[k >> 1] = (k & 1) ? ((pw[k >> 1] & 0x0000FFFFu) | (wk << 16)) : ((pw[k >> 1] & 0xFFFF0000u) | wk);
                                 }
                             }
@@ -1335,6 +1409,8 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                     acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m1.v, b1.v, acc[gi], 0, 0, 0);
                 }
             }
+            GM_PH_STAMP(ph_c3);
+            GM_PH_ADD(4, ph_c3 - ph_c2);   // pair loops of the chunk
         }
         row0 += 32;
         if (!FINE || row0 >= nrows_all) break;
@@ -1343,6 +1419,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         // ---- D[row][query]: lane (q, h) of group g holds rows (k & 3) + 8 (k >> 2) + 4 h in acc[g][k].  A lane's home
         // query is query (lane & 31) of group (lane >> 5): it keeps its own half of that group's rows and swaps the
         // other group's registers with lane ^ 32 for the missing half.
+        GM_PH_STAMP(ph_t3);
         float own[16], got[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -1368,6 +1445,18 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         const float4 qe = spts4[qidx_e];
         const bool vox_ok = emit_normal(active, qe, mom, vd, normals4, counts, qn, stat_t0);
         if (vd.enabled) voxel_sums(vox_ok, qe, vd, vox_table);
+        GM_PH_STAMP(ph_t4);
+        GM_PH_ADD(5, ph_t4 - ph_t3);   // moments -> normal, stores, voxel sums
+        GM_PH_ADD(6, ph_t4 - ph_t0);   // the whole tile
+        GM_PH_ADD(7, 1);
+#ifdef GM_NORMALS_PHASES
+        if (lane < 8) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v = lane == k ? ph_acc[k] : v;
+            atomicAdd(&gm_phase_ticks[lane], (unsigned long long)v);
+        }
+#endif
     }
 }
 
@@ -1393,7 +1482,8 @@ __device__ __forceinline__ uint32_t normals_wave_id(const NormalsArgs &A, uint32
             vblock = ((slot / cb) * 8u + xcd) * cb + slot % cb;
         }
     }
-    return vblock * kNrWaves + threadIdx.x / kWave;
+    // (wave-uniform by construction; saying so keeps it, and everything derived from it, in scalar registers)
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(vblock * kNrWaves + threadIdx.x / kWave));
 }
 
 __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals_m(NormalsArgs A, uint32_t mx_min_candidates)
@@ -1422,16 +1512,17 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs
     const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
     // (the grid is sized for the most tiles a frame of this size can have: most of its waves find no tile and leave here)
     if (wave_id >= ntiles) return;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));   // (scalar: the slice's address costs no vector register)
     // slots the staging never writes (past a chunk's end, the two pad rows) are read as MFMA operands whose products are
     // masked or land in unused result rows: they only have to be FINITE
     {
-        uint4 *z = reinterpret_cast<uint4 *>(lds[threadIdx.x / kWave]);
+        uint4 *z = reinterpret_cast<uint4 *>(lds[wv]);
         for (int i = lane_id(); i < kMdWaveLdsBytes / 16; i += kWave) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    normals_tile_mxd<FINE>(A, lds[threadIdx.x / kWave], A.tiles[wave_id], mx_min_candidates);
+    normals_tile_mxd<FINE>(A, lds[wv], A.tiles[wave_id], mx_min_candidates);
     if (ntiles > n_waves && wave_id != 0xFFFFFFFFu)
         for (uint32_t t = wave_id + n_waves; t < ntiles; t += n_waves)
-            normals_tile_mxd<FINE>(A, lds[threadIdx.x / kWave], A.tiles[t], mx_min_candidates);
+            normals_tile_mxd<FINE>(A, lds[wv], A.tiles[t], mx_min_candidates);
 }
 
 // the all-VALU formulation of every tile (GM_NORMALS_IMPL=valu: A/B measurements and the cross-check in tests)
@@ -1518,3 +1609,15 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
 }
 
 }  // namespace gm
+
+#ifdef GM_NORMALS_PHASES
+// diagnostic builds only: read (and clear) the phase tick sums of k_normals
+extern "C" int gm_debug_phases(unsigned long long *out16)
+{
+    hipDeviceSynchronize();
+    int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(gm::gm_phase_ticks), sizeof(unsigned long long) * 16);
+    unsigned long long z[16] = {};
+    if (rc == 0) rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(gm::gm_phase_ticks), z, sizeof(z));
+    return rc;
+}
+#endif

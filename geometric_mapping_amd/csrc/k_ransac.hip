@@ -9,14 +9,18 @@
 // oracle/gm_oracle_ext.c.  Parity for everything here is "vs the build's own
 // restatement + analytic truth", never "vs reference".
 //
-// Scoring kernel shape (HBM-streaming in points, compute-bound in H):
-//   lane <-> point (8 points per lane held in registers, loaded once, coalesced 16 B),
-//   hypotheses are wave-uniform: they arrive through scalar loads (SGPR operands),
-//   an inlier test is 3 v_fma + 1 v_cmp whose result IS the wave ballot (SGPR pair),
-//   s_bcnt1 counts it; per-block sums go through LDS, per-block rows to HBM with plain
-//   stores, and a second kernel sums the rows in fixed order and picks the arg-max.
-//   No float atomics anywhere: counts are integers, results are run-to-run identical.
-// (k_score / k_score_sel, the scorers actually used, map lane <-> hypothesis: see their comments.)
+// Shape of the scorers (k_score / k_score_sel, the only ones launched):
+//   lane <-> hypothesis: a lane keeps ITS one or two hypotheses in registers with a private integer
+//   inlier counter; a block's points are staged once in LDS (coalesced 16 B loads, masked points
+//   become NaN) as groups of four, SoA inside a group, and every lane walks them through broadcast
+//   ds_read_b128 -- the inner loop is pure VALU (plane: 3 fma + compare + add-with-carry), no
+//   ballots, no SALU, no atomics; one integer atomicAdd per (block, hypothesis) closes a block.
+//   Counts are integers and integer adds commute: results are run-to-run identical.
+//   In-frame scoring is preemptive (launch_score_preemptive): all H hypotheses on every 64th point
+//   -> the 128 best -> those on every 16th point -> the 8 best -> those on every point; the top-K
+//   selection of a stage runs in the last block of the scoring launch before it (a done-counter and a
+//   4-bit radix select over keys held in registers), so a model costs five launches.
+//   Bound: fp32 VALU for the scorers, HBM for the label pass (which also sums the segment's moments).
 #include "gm_internal.hpp"
 
 namespace gm {

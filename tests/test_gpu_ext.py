@@ -218,10 +218,12 @@ def test_full_size_properties_10m_plane_and_cylinder(gm, oc):
     assert np.array_equal(res2["scatter"], res["scatter"]) and np.array_equal(res2["cylinder"], res["cylinder"])
 
 
-@pytest.mark.parametrize("H", [32, 33, 256, 257])
+@pytest.mark.parametrize("H", [7, 8, 9, 127, 128, 129])
 def test_frame_ransac_stage_boundaries(gm, oc, H):
-    """The staged scoring switches shape at H = 32 (exhaustive) and H = 256 (two stages instead of three): the plane
-    winner must equal the restated staging on the oracle's scorer on both sides of each boundary."""
+    """The staged scoring switches shape at H = 8 (at or below: exhaustive, every hypothesis on every point) and at
+    H = 128 (at or below: two stages, every 16th point then every point; above: three, starting on every 64th point;
+    include/gm_hip.h, csrc/k_ransac.hip launch_score_preemptive): the plane winner must equal the restated staging
+    (preemptive_best above) on the oracle's scorer at, just below and just above each boundary."""
     from geometric_mapping_amd import _lib
     xyz = synth.tunnel_frame(50000, seed=4, floor_z=-1.2, outlier_frac=0.01)
     with gm.GeometricMapping(flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_RANSAC_PLANE, ransac_hypotheses=H,

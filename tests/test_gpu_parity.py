@@ -457,6 +457,46 @@ def test_normals_grid_stride_path_is_bitwise_identical(gm):
         assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
 
 
+def test_chained_scan_epochs_wrap_cleanly(gm):
+    """The chained scans tag their records with an epoch that wraps (host counter: every 2^29 - 2 launches of a slot;
+    replayed graphs: every 2^26 frames).  At the wrap the record array is cleared so that no record of the previous
+    period can read as ready.  The counters are started just below the wrap (GM_TEST_*, read at context creation -> child
+    processes): frames of changing size on either side of it must be the frames of an ordinary context, bit for bit."""
+    import subprocess, sys, tempfile, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import geometric_mapping_amd as g\n"
+        "from geometric_mapping_amd import synth, _lib\n"
+        "flags = _lib.GM_CFG_DEFAULT | int(sys.argv[2])\n"
+        "out = {}\n"
+        "with g.GeometricMapping(neighborRadius=0.25, flags=flags) as c:\n"
+        "    for i, n in enumerate([90000, 5000, 90000, 20000, 90000, 300, 90000, 40000]):\n"
+        "        xyz = synth.tunnel_frame(n, seed=30 + i, floor_z=-1.2, outlier_frac=0.01)\n"
+        "        res = c.process_frame(xyz)\n"
+        "        out['cloud%%d' %% i] = c.cropped_cloud()[0]; out['rows%%d' %% i] = c.cropped_cloud()[1]\n"
+        "        out['nrm%%d' %% i] = c.normals(); out['scatter%%d' %% i] = res['scatter']; out['cen%%d' %% i] = c.voxel_centroids()[0]\n"
+        "np.savez(sys.argv[1], **out)\n"
+    ) % root
+    from geometric_mapping_amd import _lib
+    with tempfile.TemporaryDirectory() as d:
+        runs = {}
+        for tag, flags, extra in (("plain", 0, {}), ("host_wrap", 0, {"GM_TEST_SCAN_EPOCH": str(0x1FFFFFFE - 7)}),
+                                  ("graph", _lib.GM_CFG_GRAPH, {}),
+                                  ("graph_wrap", _lib.GM_CFG_GRAPH, {"GM_TEST_FRAME_COUNTER": str(0x2000000 - 3)}),
+                                  ("graph_wrap2", _lib.GM_CFG_GRAPH, {"GM_TEST_FRAME_COUNTER": str(0x4000000 - 3)})):
+            env = dict(os.environ)
+            env.pop("GM_TEST_SCAN_EPOCH", None); env.pop("GM_TEST_FRAME_COUNTER", None)
+            env.update(extra)
+            f = os.path.join(d, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f, str(flags)], env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr
+            runs[tag] = dict(np.load(f))
+    for tag in ("host_wrap", "graph", "graph_wrap", "graph_wrap2"):
+        for k in runs["plain"]:
+            assert np.array_equal(runs["plain"][k], runs[tag][k], equal_nan=True), (tag, k)
+
+
 def test_pinned_host_rows_equal_pageable_rows(gm, oc):
     """GM_CLOUD_PINNED (rows in gm_host_alloc memory, no staging copy) is the same frame as pageable input, also when
     the frames are submitted asynchronously from two pinned buffers."""
