@@ -658,14 +658,6 @@ gm_status gm_host_free(gm_ctx *ctx, void *ptr)
 
 uint32_t gm_abi_version(void) { return GM_ABI_VERSION; }
 
-#ifdef GM_NORMALS_STATS
-// diagnostic builds only: raw device counters of a slot (16 words)
-extern "C" int gm_debug_counters(gm_ctx *ctx, uint32_t slot, uint32_t *out)
-{
-    hipDeviceSynchronize();
-    return (int)hipMemcpy(out, ctx->slots[slot].ctr, sizeof(gm::DevCounters), hipMemcpyDeviceToHost);
-}
-#endif
 
 const char *gm_status_string(gm_status s)
 {

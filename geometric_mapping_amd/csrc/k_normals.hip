@@ -991,14 +991,21 @@ constexpr int kMdOctets = kMdSlots / 8;
 constexpr int kMdOctetWords = 33 * 4;               // 31 feature rows (1 + 9 + 18 + 3) + 2 pad rows = 528 B: 132 dwords = 4 mod 32 banks
 constexpr int kMdWaveLdsBytes = (kMdOctets * kMdOctetWords + 16) * 4;
 
-// feature row behind k-slot s of the distance product (candidate side); the query side holds, slot for slot,
-// 1,1,1 | |v|^2 h,m,l | -2v: h,m,l,h,m,h per coordinate | 0
-__device__ __forceinline__ uint32_t md_row_of_slot(int s)
+// Feature rows of the image (one 16-byte row = eight candidates' bf16 values of one feature), ordered so that the FOUR
+// transposed reads a lane issues per 32-candidate block for the distance product hit four CONSECUTIVE rows: one address
+// register and three immediate offsets.  A lane's reads serve the k-slots b, b+4, b+16, b+20 of the product
+// (b = 8 (lane >> 5) + ((lane & 15) >> 2)); slot b + {0,4,16,20} <-> row w(b) + {0,1,2,3}:
+//     row  0: 1          1: u_x hi    2: u_y hi    3: u_z hi        window 0 (b = 0, 1, 2): against r2-|v|^2 and 2v, hi / mid / lo
+//     row  4: u_x mid    5: u_y mid   6: u_z mid   7: |u|^2 mid     window 4 (b = 3: against 2v hi, -1;  b = 8: 2v mid, 0)
+//     row  8: u_x lo     9: u_y lo   10: u_z lo   11: |u|^2 hi      window 8 (b = 9: against 2v hi, -1)
+//     row 12: |u|^2 lo  13..30: the six products u_a u_b, hi / mid / lo each                window 12 (b = 10: -1, 0, 0, 0)
+// (b = 11 carries zeros.)  The 24 products kept are the ones of round 2: (hi,hi) (mid,hi) (lo,hi) (hi,mid) (mid,mid)
+// (hi,lo) per coordinate, the three terms of |u|^2 against -1 and of r2 - |v|^2 against 1.
+constexpr int kRowX[3] = {1, 4, 8}, kRowY[3] = {2, 5, 9}, kRowZ[3] = {3, 6, 10}, kRowQ[3] = {11, 7, 12};   // hi, mid, lo
+constexpr int kRowProd0 = 13;
+__device__ __forceinline__ uint32_t md_window_of_base(int b)   // first row of the four a lane with slot base b reads
 {
-    if (s < 3) return 28u + (uint32_t)s;            // |u|^2 h, m, l
-    if (s < 6 || s >= 24) return 0u;                // the constant-1 row (query side: |v|^2 terms / zero)
-    const int c = (s - 6) / 6, j = (s - 6) % 6;     // coordinate, position in (h,h,h,m,m,l)
-    return 1u + 3u * (uint32_t)c + (j < 3 ? 0u : (j < 5 ? 1u : 2u));
+    return b < 3 ? 0u : ((b == 3 || b == 8) ? 4u : (b == 9 ? 8u : (b == 10 ? 12u : 0u)));
 }
 // fp32 -> three bf16 bit patterns (exact: 8 + 8 + 8 mantissa bits, truncation)
 __device__ __forceinline__ void md_split3(float a, uint32_t out[3])
@@ -1050,13 +1057,9 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
     const int qsel = lane & 31, half = lane >> 5;
     // lane roles of the transposed reads that build the distance MFMA's A fragment (see the header of this section)
     const int tq = (lane & 15) >> 2, tp = lane & 3, tr0 = 16 * ((lane >> 4) & 1);
-    uint32_t rowoff[2][2];   // byte offset of this lane's transposed reads inside a 32-candidate block: feature row + candidate quad
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-            rowoff[t][e] = md_row_of_slot(16 * t + 8 * half + 4 * e + tq) * 16u +
-                           (uint32_t)((tr0 + 4 * tp) >> 3) * (uint32_t)(kMdOctetWords * 4) + (uint32_t)((tr0 + 4 * tp) & 7) * 2u;
+    // byte offset of this lane's transposed reads inside a 32-candidate block: first row of its window + candidate quad
+    const uint32_t tr_off = md_window_of_base(8 * half + tq) * 16u +
+                            (uint32_t)((tr0 + 4 * tp) >> 3) * (uint32_t)(kMdOctetWords * 4) + (uint32_t)((tr0 + 4 * tp) & 7) * 2u;
     const uint32_t mom_off = (uint32_t)qsel * 16u + 8u * (uint32_t)half;   // ... and of its moment-MFMA operand reads
     {
         const uint32_t qs = tile.x, qn = tile.y;
@@ -1090,17 +1093,27 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         // usual grid): 9 rows, one pass.
         const int gD = FINE ? g.D : 1;
         const int side = 2 * gD + 1, nrows_all = side * side;
+        // Window ends per (row, group).  FINE: lane i holds both ends of (row i / 2 of the pass, group i % 2) in sb / se.  The
+        // usual grid: ONE end per lane -- lane 2 k holds the begin, lane 2 k + 1 the end of (row k / 2, group k % 2) in sb --
+        // so the 36 searches of a tile run on 36 lanes instead of two apiece on 18: half the instructions per round.
         uint32_t sb = 0, se = 0;
         int nrows = 0;   // rows of the current pass
+        auto win_begin = [&](int r, int gg) -> uint32_t {
+            return FINE ? __builtin_amdgcn_readlane(sb, r * kMxGroups + gg) : __builtin_amdgcn_readlane(sb, 2 * (r * kMxGroups + gg));
+        };
+        auto win_end = [&](int r, int gg) -> uint32_t {
+            return FINE ? __builtin_amdgcn_readlane(se, r * kMxGroups + gg) : __builtin_amdgcn_readlane(sb, 2 * (r * kMxGroups + gg) + 1);
+        };
         auto find_windows = [&](int row0) {
             nrows = nrows_all - row0 < 32 ? nrows_all - row0 : 32;
             sb = 0; se = 0;
-            const int r = row0 + (lane >> 1), gg = lane & 1;
+            const int k = FINE ? lane : (lane >> 1);     // (row, group) this lane works for
+            const int r = row0 + (k >> 1), gg = k & 1;
             const int lo_fx = __shfl(fxl, gg * kMxGroupLanes, kWave);
             const int hi_fx = __shfl(fxl, gg * kMxGroupLanes + kMxGroupLanes - 1, kWave);
             const int a = (r % side) - gD, b = (r / side) - gD;
             const int yy = cy + a, zz = cz + b;
-            const int reach = (lane >> 1) < nrows ? (FINE ? (int)g.reach[a < 0 ? -a : a][b < 0 ? -b : b] : g.xreach) : 0;
+            const int reach = (k >> 1) < nrows ? (FINE ? (int)g.reach[a < 0 ? -a : a][b < 0 ? -b : b] : g.xreach) : 0;
             uint32_t key_b = 0, key_e = 0, lo1 = 0, hi1 = 0;
             if (reach > 0 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
                 const uint32_t nrow = (uint32_t)(zz * g.ny + yy);
@@ -1111,14 +1124,24 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                 key_b = rbk + (uint32_t)xa; key_e = rbk + (uint32_t)xb + 1u;
                 lo1 = rb.x; hi1 = rb.y;
             }
-            uint32_t lo2 = lo1, hi2 = hi1;
-            while (lo1 < hi1 || lo2 < hi2) {
-                const uint32_t m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
-                const uint32_t k1 = skeys[m1 < n ? m1 : n - 1u], k2 = skeys[m2 < n ? m2 : n - 1u];
-                if (lo1 < hi1) { if (k1 < key_b) lo1 = m1 + 1u; else hi1 = m1; }
-                if (lo2 < hi2) { if (k2 < key_e) lo2 = m2 + 1u; else hi2 = m2; }
+            if (FINE) {
+                uint32_t lo2 = lo1, hi2 = hi1;
+                while (lo1 < hi1 || lo2 < hi2) {
+                    const uint32_t m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
+                    const uint32_t k1 = skeys[m1 < n ? m1 : n - 1u], k2 = skeys[m2 < n ? m2 : n - 1u];
+                    if (lo1 < hi1) { if (k1 < key_b) lo1 = m1 + 1u; else hi1 = m1; }
+                    if (lo2 < hi2) { if (k2 < key_e) lo2 = m2 + 1u; else hi2 = m2; }
+                }
+                sb = lo1; se = lo2;
+            } else {
+                // (searching 5, 9 or 17 ways per round -- a third of the dependent round trips -- was measured: no change)
+                const uint32_t key = (lane & 1) ? key_e : key_b;   // first position of the row whose key is >= key
+                while (lo1 < hi1) {
+                    const uint32_t m1 = (lo1 + hi1) >> 1;
+                    if (skeys[m1] < key) lo1 = m1 + 1u; else hi1 = m1;   // (m1 < hi1 <= n)
+                }
+                sb = lo1;
             }
-            sb = lo1; se = lo2;
         };
         find_windows(0);
         GM_PH_STAMP(ph_t1);
@@ -1134,7 +1157,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             uint32_t wl = 0;
 #pragma unroll
             for (int r = 0; r < 9; ++r)
-                wl += __builtin_amdgcn_readlane(se, r * kMxGroups) - __builtin_amdgcn_readlane(sb, r * kMxGroups);
+                wl += win_end(r, 0) - win_begin(r, 0);
             thin = wl < min_candidates;
         }
         // one origin per tile: the tile's middle query snapped to a multiple of g.snap (a power of two >= one ulp of the
@@ -1176,31 +1199,22 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             const float S = g.dscale;
             md_split3(__fsub_rn(g.r2, vv) * S, sv); md_split3(2.0f * S * vx, sx); md_split3(2.0f * S * vy, sy); md_split3(2.0f * S * vz, sz);
             const uint32_t one = __float_as_uint(-S) >> 16;   // bf16(-dscale)
-            // k-slots 0..31: 1,1,1 | vv h,m,l | x: h,m,l,h,m,h | y: ... | z: ... | 0 x 8   (16-bit patterns)
-            const uint32_t s0[8] = {one, one, one, sv[0], sv[1], sv[2], sx[0], sx[1]};            // slots 0..7
-            const uint32_t s1[8] = {sx[2], sx[0], sx[1], sx[0], sy[0], sy[1], sy[2], sy[0]};      // slots 8..15
-            const uint32_t s2[8] = {sy[1], sy[0], sz[0], sz[1], sz[2], sz[0], sz[1], sz[0]};      // slots 16..23
+            // 16-bit patterns of this lane's eight k-slots per K-step: slot 16 t + 8 half + j <-> base 8 half + (j & 3),
+            // row offset 2 t + (j >> 2) of that base's window (table in front of md_window_of_base)
+            const uint32_t lo0[8] = {sv[0], sv[1], sv[2], sx[0], sx[0], sx[1], sx[2], sy[0]};   // half 0, K-step 0
+            const uint32_t lo1[8] = {sy[0], sy[1], sy[2], sz[0], sz[0], sz[1], sz[2], one};     // half 0, K-step 1
+            const uint32_t hi0[8] = {sx[1], sx[0], one, 0u, sy[1], sy[0], 0u, 0u};              // half 1, K-step 0
+            const uint32_t hi1[8] = {sz[1], sz[0], 0u, 0u, 0u, one, 0u, 0u};                    // half 1, K-step 1
             union { bf16x8 v; uint32_t u[4]; } f0, f1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f0.u[j] = half ? (s1[2 * j] | (s1[2 * j + 1] << 16)) : (s0[2 * j] | (s0[2 * j + 1] << 16));
-                f1.u[j] = half ? 0u : (s2[2 * j] | (s2[2 * j + 1] << 16));                        // slots 24..31: zero
+                f0.u[j] = half ? (hi0[2 * j] | (hi0[2 * j + 1] << 16)) : (lo0[2 * j] | (lo0[2 * j + 1] << 16));
+                f1.u[j] = half ? (hi1[2 * j] | (hi1[2 * j + 1] << 16)) : (lo1[2 * j] | (lo1[2 * j + 1] << 16));
             }
             qb[gi][0] = f0.v; qb[gi][1] = f1.v;
         }
-        auto row_begin = [&](int r) -> uint32_t { return __builtin_amdgcn_readlane(sb, r * kMxGroups); };
-        auto row_end = [&](int r) -> uint32_t { return __builtin_amdgcn_readlane(se, r * kMxGroups + ngroups - 1); };
-        int nr = 0;
-        uint32_t nc0 = 0, nlen = 0;
-        auto seek = [&](int r, uint32_t c) {
-            nlen = 0;
-            while (r < nrows) {
-                const uint32_t e = row_end(r);
-                if (c < e) { nr = r; nc0 = c; nlen = (e - c < (uint32_t)kMdChunk) ? e - c : (uint32_t)kMdChunk; return; }
-                ++r;
-                if (r < nrows) c = row_begin(r);
-            }
-        };
+        auto row_begin = [&](int r) -> uint32_t { return win_begin(r, 0); };
+        auto row_end = [&](int r) -> uint32_t { return win_end(r, ngroups - 1); };
         if (thin) {
             // direct path, self-contained: every lane tests its own query against every candidate of the tile's row
             // ranges (wave-uniform loads straight from the sorted cloud) and sums the offsets from the query in fp64
@@ -1225,30 +1239,82 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         }
         GM_PH_STAMP(ph_t2);
         GM_PH_ADD(1, ph_t2 - ph_t1);   // origin, query-side operand fragments
-        // ---- the candidate stream.  A chunk's rows are fetched one chunk AHEAD: the loads of chunk i+1 are issued right
-        // after chunk i has been staged and stay in flight, in six registers, while the wave runs chunk i's pair loops --
-        // a wave owns its LDS slice, nothing else can hide that round trip (it used to be paid twice per chunk, once per
-        // candidate of the lane's pair, with the wave idle: a quarter of a tile's lifetime).  Lane l takes candidates
-        // 2l and 2l+1 of the chunk (two bf16 of a feature row make one dword); a lane past the end re-reads the chunk's
-        // last row, so every lane's loads are unconditional.
-        static_assert(kMdChunk == 2 * kWave, "one candidate pair per lane and chunk");
-        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
-        auto fetch_chunk = [&](uint32_t c0, uint32_t clen) {
-            const uint32_t i = 2u * (uint32_t)lane, last = clen - 1u;
-            pa = spts4[c0 + (i < last ? i : last)];
-            pb = spts4[c0 + (i + 1u < last ? i + 1u : last)];
+        // ---- the candidate stream.  The tile's candidates -- the windows of its (2D+1)^2 rows, one after the other -- are
+        // cut into chunks of up to kMdChunk image slots.  A chunk holds up to kMdPieces pieces, each a run of one row's window
+        // starting on an octet of slots, so that chunks are full: the rest of one row's window and the head of the next
+        // share a chunk instead of leaving most of its lanes idle when it is staged.
+        // Per group the pieces' clipped windows are covered by ONE run of 32-candidate blocks [lo, hi): what lies between
+        // two windows is not a neighbour of any query of the group (a window is a superset of its neighbours), and every
+        // slot that holds no candidate is marked far.  Chunks are assembled one AHEAD: the rows of chunk i+1 are loaded
+        // right after chunk i has been staged and stay in flight, in registers, while the wave runs chunk i's pair loops.
+        // Lane l stages slots 2l and 2l+1 (two bf16 of a feature row make one dword).
+        static_assert(kMdChunk == 2 * kWave, "one slot pair per lane and chunk");
+        constexpr int kMdPieces = 4;
+        int cur_r = 0, row0 = 0;                  // cursor: row of the pass (first row of the pass), ...
+        uint32_t cur_c = row_begin(0);            // ... next unread position of its window
+        uint32_t n_lo[kMxGroups], n_hi[kMxGroups], n_slots = 0;   // the chunk being fetched: block range per group, slots used
+        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;    // its rows (this lane's slot pair)
+        uint32_t pidx = qs, pv = 0;               // sorted position of the pair's first candidate; bit 0 / 1: first / second slot holds one
+        auto assemble = [&]() {
+            n_slots = 0; pv = 0; pidx = qs;
+#pragma unroll
+            for (int gi = 0; gi < kMxGroups; ++gi) { n_lo[gi] = 0xFFFFFFFFu; n_hi[gi] = 0u; }
+            int pieces = 0;
+            for (;;) {   // wave-uniform
+                if (cur_r >= nrows) {   // the pass has no rows left
+                    if (!FINE || row0 + 32 >= nrows_all) break;
+                    row0 += 32;
+                    find_windows(row0);   // the next pass of rows (finer grids only)
+                    cur_r = 0; cur_c = row_begin(0);
+                    continue;
+                }
+                const uint32_t e = row_end(cur_r);
+                if (cur_c >= e) {
+                    ++cur_r;
+                    if (cur_r < nrows) cur_c = row_begin(cur_r);
+                    continue;
+                }
+                const uint32_t len = e - cur_c, room = (uint32_t)kMdChunk - n_slots;
+                const uint32_t take = len < room ? len : room;
+#pragma unroll
+                for (int gi = 0; gi < kMxGroups; ++gi) {
+                    if (gi >= ngroups) break;
+                    const uint32_t mb = win_begin(cur_r, gi), me = win_end(cur_r, gi);
+                    uint32_t ob = mb > cur_c ? mb - cur_c : 0u, oe = me > cur_c ? me - cur_c : 0u;
+                    if (ob > take) ob = take;
+                    if (oe > take) oe = take;
+                    if (oe > ob) {
+                        const uint32_t l = n_slots + (ob & ~7u), h = n_slots + oe;
+                        n_lo[gi] = l < n_lo[gi] ? l : n_lo[gi];
+                        n_hi[gi] = h > n_hi[gi] ? h : n_hi[gi];
+                    }
+                }
+                {
+                    const uint32_t i = 2u * (uint32_t)lane;
+                    const bool in = i >= n_slots && i < n_slots + take;
+                    pidx = in ? cur_c + (i - n_slots) : pidx;
+                    pv = in ? (i + 1u < n_slots + take ? 3u : 1u) : pv;
+                }
+                n_slots += (take + 7u) & ~7u;
+                cur_c += take;
+                ++pieces;
+                if (n_slots >= (uint32_t)kMdChunk || pieces == kMdPieces) break;
+            }
+            if (n_slots) {   // (lanes without a candidate re-read the tile's first query: every lane's loads are unconditional)
+                pa = spts4[pidx];
+                pb = spts4[pidx + (pv >> 1)];
+            }
         };
-        for (int row0 = 0;;) {
-        seek(0, row_begin(0));
-        if (nlen) fetch_chunk(nc0, nlen);
-        while (nlen) {
-            const int r = nr;
-            const uint32_t c0 = nc0, clen = nlen;
+        assemble();
+        while (n_slots) {
+            uint32_t c_lo[kMxGroups], c_hi[kMxGroups];
+#pragma unroll
+            for (int gi = 0; gi < kMxGroups; ++gi) { c_lo[gi] = n_lo[gi]; c_hi[gi] = n_hi[gi]; }
+#ifdef GM_NORMALS_STATS
+            const uint32_t c_slots = n_slots;
+#endif
             wave_lds_fence();  // previous chunk fully consumed
             GM_PH_STAMP(ph_c0);
-#if !GM_NORMALS_PREFETCH
-            fetch_chunk(c0, clen);
-#endif
 #ifdef GM_NORMALS_PHASES
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             GM_PH_STAMP(ph_c1);
@@ -1257,43 +1323,47 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             // ---- stage the chunk
             {
                 const uint32_t i = 2u * (uint32_t)lane;
-                if (i < clen) {
-                    const bool vb = i + 1u < clen;
+                const uint32_t oct = i >> 3;
+                uint32_t *fo = feat + oct * (uint32_t)kMdOctetWords + ((i & 7u) >> 1);
+                auto st = [&](int frow, uint32_t v) { fo[frow * 4] = v; };
+                if (pv & 1u) {
+                    const bool vb = (pv & 2u) != 0u;
                     const float4 ca = pa, cb = pb;
                     const float uxa = ca.x - ox, uya = ca.y - oy, uza = ca.z - oz;
                     const float uxb = vb ? cb.x - ox : 0.f, uyb = vb ? cb.y - oy : 0.f, uzb = vb ? cb.z - oz : 0.f;
-                    const uint32_t oct = i >> 3;
-                    uint32_t *fo = feat + oct * (uint32_t)kMdOctetWords + ((i & 7u) >> 1);
-                    auto st = [&](int frow, uint32_t v) { fo[frow * 4] = v; };
-                    auto split3 = [&](float a, float b, int frow) {  // exact: 8 + 8 + 8 mantissa bits
+                    auto split3 = [&](float a, float b, int rh, int rm, int rl) {  // exact: 8 + 8 + 8 mantissa bits
                         const uint32_t ah = __float_as_uint(a) & 0xFFFF0000u, bh = __float_as_uint(b) & 0xFFFF0000u;
-                        st(frow, pack_hi16(bh, ah));
+                        st(rh, pack_hi16(bh, ah));
                         const float ra = a - __uint_as_float(ah), rb = b - __uint_as_float(bh);
                         const uint32_t am = __float_as_uint(ra) & 0xFFFF0000u, bm = __float_as_uint(rb) & 0xFFFF0000u;
-                        st(frow + 1, pack_hi16(bm, am));
+                        st(rm, pack_hi16(bm, am));
                         const float sa = ra - __uint_as_float(am), sb2 = rb - __uint_as_float(bm);
-                        st(frow + 2, pack_hi16(__float_as_uint(sb2), __float_as_uint(sa)));
+                        st(rl, pack_hi16(__float_as_uint(sb2), __float_as_uint(sa)));
                     };
+                    auto prod3 = [&](float a, float b, int k) { split3(a, b, kRowProd0 + 3 * k, kRowProd0 + 3 * k + 1, kRowProd0 + 3 * k + 2); };
                     st(0, 0x3F803F80u);  // the count row: 1.0 | 1.0
-                    split3(uxa, uxb, 1); split3(uya, uyb, 4); split3(uza, uzb, 7);
+                    split3(uxa, uxb, kRowX[0], kRowX[1], kRowX[2]); split3(uya, uyb, kRowY[0], kRowY[1], kRowY[2]);
+                    split3(uza, uzb, kRowZ[0], kRowZ[1], kRowZ[2]);
                     const float xxa = uxa * uxa, yya = uya * uya, zza = uza * uza, xxb = uxb * uxb, yyb = uyb * uyb, zzb = uzb * uzb;
-                    split3(xxa, xxb, 10); split3(uxa * uya, uxb * uyb, 13); split3(uxa * uza, uxb * uzb, 16);
-                    split3(yya, yyb, 19); split3(uya * uza, uyb * uzb, 22); split3(zza, zzb, 25);
+                    prod3(xxa, xxb, 0); prod3(uxa * uya, uxb * uyb, 1); prod3(uxa * uza, uxb * uzb, 2);
+                    prod3(yya, yyb, 3); prod3(uya * uza, uyb * uzb, 4); prod3(zza, zzb, 5);
                     // |u|^2; a missing second candidate of the pair is "far" (2^100: d2 = 2^100 + ... never within r2)
-                    split3(__fadd_rn(__fadd_rn(xxa, yya), zza), vb ? __fadd_rn(__fadd_rn(xxb, yyb), zzb) : 0x1p100f, 28);
+                    split3(__fadd_rn(__fadd_rn(xxa, yya), zza), vb ? __fadd_rn(__fadd_rn(xxb, yyb), zzb) : 0x1p100f, kRowQ[0], kRowQ[1], kRowQ[2]);
+                    // the candidates' sorted positions, in the octet's two spare rows: the rare exact re-evaluation of a pair
+                    // finds its candidate through them
+                    *reinterpret_cast<uint2 *>(feat + oct * (uint32_t)kMdOctetWords + 31u * 4u + (i & 7u)) = make_uint2(pidx, pidx + 1u);
+                } else {
+                    // a slot pair without candidates (between two pieces, behind the last one): far (the other rows are stale
+                    // but finite, the weights come out 0 like any other far candidate's: no index masks in the pair loop)
+                    st(kRowQ[0], 0x71807180u);   // |u|^2 hi := bf16(2^100) | bf16(2^100)
                 }
-            }
-            // slots behind the chunk that a group's last 32-candidate block may still read: far as well (their other rows
-            // are stale but finite, their weights come out 0 like any other far candidate's: no index masks in the loop)
-            {
-                const uint32_t i = ((clen + 1u) & ~1u) + 2u * (uint32_t)lane;
-                if (lane < 16 && i < (uint32_t)kMdSlots)
-                    feat[(i >> 3) * (uint32_t)kMdOctetWords + ((i & 7u) >> 1) + 28u * 4u] = 0x71807180u;   // bf16(2^100) | bf16(2^100)
+                // slots behind the chunk that a group's last 32-candidate block may still read
+                if (lane < (kMdSlots - kMdChunk) / 2)
+                    feat[((uint32_t)kMdChunk / 8u + ((uint32_t)lane >> 2)) * (uint32_t)kMdOctetWords + ((uint32_t)lane & 3u) + (uint32_t)kRowQ[0] * 4u] = 0x71807180u;
             }
             wave_lds_fence();
-            if (c0 + clen < row_end(r)) seek(r, c0 + clen); else seek(r + 1, r + 1 < nrows ? row_begin(r + 1) : 0u);
 #if GM_NORMALS_PREFETCH
-            if (nlen) fetch_chunk(nc0, nlen);   // in flight during the pair loops below
+            assemble();   // the next chunk: its rows are in flight during the pair loops below
 #endif
             GM_PH_STAMP(ph_c2);
 #ifdef GM_NORMALS_PHASES
@@ -1302,21 +1372,14 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
 #pragma unroll
             for (int gi = 0; gi < kMxGroups; ++gi) {
                 if (gi >= ngroups) break;  // wave-uniform
-                // this group's window inside the chunk, start aligned down to an octet
-                const uint32_t mb = __builtin_amdgcn_readlane(sb, r * kMxGroups + gi),
-                               me = __builtin_amdgcn_readlane(se, r * kMxGroups + gi);
-                uint32_t ob = mb > c0 ? mb - c0 : 0u, oe = me > c0 ? me - c0 : 0u;
-                if (ob > clen) ob = clen;
-                if (oe > clen) oe = clen;
-                ob &= ~7u;
+                const uint32_t ob8 = c_lo[gi], oe = c_hi[gi];
 #if defined(GM_NORMALS_STATS) && !defined(GM_MD_DEBUG)
                 if (lane == 0) {
-                    atomicAdd(&ctr->pad[0], (oe > ob ? ((oe - ob + 31u) >> 5) * 32u : 0u) / 2u);  // candidates streamed per query, in 64-query tile units
-                    atomicAdd(&ctr->pad[1], (oe > ob ? oe - ob : 0u) * 2u);
-                    if (gi == 0) { atomicAdd(&ctr->pad[2], clen); atomicAdd(&ctr->pad[3], 1u); }
+                    atomicAdd(&ctr->pad[0], (oe > ob8 ? ((oe - ob8 + 31u) >> 5) * 32u : 0u) / 2u);  // candidates streamed per query, in 64-query tile units
+                    atomicAdd(&ctr->pad[1], (oe > ob8 ? oe - ob8 : 0u) * 2u);
+                    if (gi == 0) { atomicAdd(&ctr->pad[2], c_slots); atomicAdd(&ctr->pad[3], 1u); }
                 }
 #endif
-                const uint32_t ob8 = ob;   // (aligned down to an octet above)
                 const int nblk = oe > ob8 ? (int)((oe - ob8 + 31u) >> 5) : 0;   // 32-candidate blocks, wave-uniform
                 const unsigned char *fbytes = reinterpret_cast<const unsigned char *>(feat);
                 uint32_t p = ob8;
@@ -1324,10 +1387,10 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                     const unsigned char *blk = fbytes + (p >> 3) * (uint32_t)(kMdOctetWords * 4);
                     // ---- distance MFMA: D1[candidate p + r][query] over the 24 k-slots.  A fragment (candidate rows,
                     // feature k) out of the feature-major image by transposed reads: 4 rows x 16 candidates per read
-                    const unsigned char *ta = blk;
+                    const unsigned char *ta = blk + tr_off;
                     union { bf16x8 v; s4 h[2]; } a0, a1;
-                    a0.h[0] = md_tr_read(ta + rowoff[0][0]); a0.h[1] = md_tr_read(ta + rowoff[0][1]);
-                    a1.h[0] = md_tr_read(ta + rowoff[1][0]); a1.h[1] = md_tr_read(ta + rowoff[1][1]);
+                    a0.h[0] = md_tr_read(ta); a0.h[1] = md_tr_read(ta + 16);          // k-slots b, b + 4
+                    a1.h[0] = md_tr_read(ta + 32); a1.h[1] = md_tr_read(ta + 48);    // k-slots b + 16, b + 20
                     // moment MFMA's A fragments (feature row qsel, the two quads of k-step s of this lane half)
                     const unsigned char *ma = blk + mom_off;
                     union { bf16x8 v; uint2 q2[2]; } m0, m1;
@@ -1359,7 +1422,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                         for (int k = 0; k < 16; ++k) {
                             const uint32_t rk = (uint32_t)((k & 3) + 8 * (k >> 2) + 4 * half);
                             if (p + rk < oe) {
-                                const float4 c = spts4[c0 + p + rk];
+                                const float4 c = spts4[feat[((p + rk) >> 3) * (uint32_t)kMdOctetWords + 31u * 4u + ((p + rk) & 7u)]];
                                 const float dx = c.x - gq[gi][0], dy = c.y - gq[gi][1], dz = c.z - gq[gi][2];
                                 const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
                                 const float d1k = g.r2 - d1[k] / g.dscale;
@@ -1391,7 +1454,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                             const bool need = fabsf(d1[k]) < g.dband;   // (far slots are never inside the band: a real candidate)
                             if (__ballot(need)) {
                                 if (need) {
-                                    const float4 c = spts4[c0 + p + rk];
+                                    const float4 c = spts4[feat[((p + rk) >> 3) * (uint32_t)kMdOctetWords + 31u * 4u + ((p + rk) & 7u)]];
                                     const float dx = c.x - gqv.x, dy = c.y - gqv.y, dz = c.z - gqv.z;
                                     // FLANN L2_Simple: every product and sum rounded, in this order; strict d2 < r2
                                     const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
@@ -1409,12 +1472,11 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                     acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m1.v, b1.v, acc[gi], 0, 0, 0);
                 }
             }
+#if !GM_NORMALS_PREFETCH
+            assemble();
+#endif
             GM_PH_STAMP(ph_c3);
             GM_PH_ADD(4, ph_c3 - ph_c2);   // pair loops of the chunk
-        }
-        row0 += 32;
-        if (!FINE || row0 >= nrows_all) break;
-        find_windows(row0);   // the next pass of rows (finer grids only)
         }
         // ---- D[row][query]: lane (q, h) of group g holds rows (k & 3) + 8 (k >> 2) + 4 h in acc[g][k].  A lane's home
         // query is query (lane & 31) of group (lane >> 5): it keeps its own half of that group's rows and swaps the
@@ -1433,8 +1495,11 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         };
         double mom[10];
         mom[0] = frow(0);
+        mom[1] = (frow(kRowX[0]) + frow(kRowX[1])) + frow(kRowX[2]);
+        mom[2] = (frow(kRowY[0]) + frow(kRowY[1])) + frow(kRowY[2]);
+        mom[3] = (frow(kRowZ[0]) + frow(kRowZ[1])) + frow(kRowZ[2]);
 #pragma unroll
-        for (int m = 0; m < 9; ++m) mom[1 + m] = (frow(1 + 3 * m) + frow(2 + 3 * m)) + frow(3 + 3 * m);
+        for (int m = 0; m < 6; ++m) mom[4 + m] = (frow(kRowProd0 + 3 * m) + frow(kRowProd0 + 3 * m + 1)) + frow(kRowProd0 + 3 * m + 2);
 
         // The query is read again here (an L2 hit) rather than kept in registers across the whole candidate stream: the
         // kernel sits at its 128-VGPR budget and everything live across the loop that the loop does not use was being
@@ -1609,6 +1674,15 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
 }
 
 }  // namespace gm
+
+#ifdef GM_NORMALS_STATS
+// diagnostic builds only: raw device counters of a slot (16 words)
+extern "C" int gm_debug_counters(gm_ctx *ctx, uint32_t slot, uint32_t *out)
+{
+    hipDeviceSynchronize();
+    return (int)hipMemcpy(out, ctx->slots[slot].ctr, sizeof(gm::DevCounters), hipMemcpyDeviceToHost);
+}
+#endif
 
 #ifdef GM_NORMALS_PHASES
 // diagnostic builds only: read (and clear) the phase tick sums of k_normals

@@ -18,5 +18,5 @@ for tag in "$@"; do
   fi
   timeout -k 10 120 python tools/stage_times.py --flags 0 --reps 20 2>/dev/null | tail -1 | grep -o '"normals": [0-9.]*' | tee -a $out
   timeout -k 10 120 python tools/stage_times.py --flags 0 --reps 10 --radius 0.5 2>/dev/null | tail -1 | grep -o '"normals": [0-9.]*' | sed 's/normals/normals_r0.5/' | tee -a $out
-  timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*' | head -1 | tee -a $out
+  for rep in 1 2 3; do timeout -k 10 200 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | grep -o "\"ms_per_step\": [0-9.]*" | head -1 | tee -a $out; done
 done
