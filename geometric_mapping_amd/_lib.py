@@ -27,6 +27,7 @@ GM_ERR_NOT_READY = 6
 GM_ERR_UNSUPPORTED = 7
 GM_ERR_COMM = 8
 GM_GROUP_LOOPBACK = 1
+GM_GROUP_N_TIMINGS = 5
 
 GM_CFG_VOXEL_GRID = 1 << 0
 GM_CFG_NEAREST = 1 << 1
@@ -169,6 +170,14 @@ def load():
         "gm_group_last_error": (C.c_char_p, [vp]),
         "gm_group_process_frame": (C.c_int, [vp, cloudp, resp]),
         "gm_group_get_cropped_xyz": (C.c_int, [vp, fp, u32, u32p]),
+        "gm_group_get_voxel_centroids": (C.c_int, [vp, fp, u32, u32p]),
+        "gm_group_get_voxel_normals": (C.c_int, [vp, fp, u32, u32p]),
+        "gm_group_get_voxel_nearest": (C.c_int, [vp, i32p, u32, u32p]),
+        "gm_group_get_timing": (C.c_int, [vp, dp, u32]),
+        "gm_group_get_edges": (C.c_int, [vp, dp, u32, u32p]),
+        "gm_group_submit_frame": (C.c_int, [vp, cloudp]),
+        "gm_group_wait_frame": (C.c_int, [vp, resp, u32p, u32p]),
+        "gm_group_in_flight": (u32, [vp]),
     }
     for name, (res, args) in proto.items():
         fn = getattr(L, name)  # AttributeError if the .so does not export it

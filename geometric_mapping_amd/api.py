@@ -413,15 +413,76 @@ class GeometricMappingGroup:
         self._check(self._L.gm_group_process_frame(self._grp, C.byref(c), C.byref(res)))
         return GeometricMapping._result(res)
 
-    def cropped_cloud(self):
+    def _fetch(self, fn, width, dtype=np.float32):
         n = C.c_uint32(0)
-        st = self._L.gm_group_get_cropped_xyz(self._grp, None, 0, C.byref(n))
+        st = fn(self._grp, None, 0, C.byref(n))
         if st not in (GM_OK, GM_ERR_CAPACITY):
             self._check(st)
+        out = np.empty((n.value, width) if width > 1 else (n.value,), dtype=dtype)
+        if n.value:
+            self._check(fn(self._grp, out.ctypes.data_as(fn.argtypes[1]), n.value, C.byref(n)))
+        return out
+
+    def cropped_cloud(self):
+        """/choppedCloud of the sharded frame in the single-GPU order: (xyz [n,3], input row index [n])."""
+        out = self._fetch(self._L.gm_group_get_cropped_xyz, 4)
+        return out[:, :3].copy(), out[:, 3].copy().view(np.int32)
+
+    def voxel_centroids(self):
+        """(centroids [V,3], points per voxel [V]) of the sharded frame, ascending voxel-key order."""
+        a = self._fetch(self._L.gm_group_get_voxel_centroids, 4)
+        return a[:, :3].copy(), a[:, 3].astype(np.int32)
+
+    def voxel_normals(self):
+        """normals->at(kIndices[0]) per voxel centroid of the sharded frame: [V,4] (GM_CFG_NEAREST)."""
+        return self._fetch(self._L.gm_group_get_voxel_normals, 4)
+
+    def voxel_nearest(self):
+        """Index (into cropped_cloud()) of the nearest valid point of every voxel centroid (GM_CFG_NEAREST)."""
+        return self._fetch(self._L.gm_group_get_voxel_nearest, 1, np.int32)
+
+    def timing(self):
+        """Wall-clock split of the last process_frame call, milliseconds."""
+        t = (C.c_double * _lib.GM_GROUP_N_TIMINGS)()
+        self._check(self._L.gm_group_get_timing(self._grp, t, _lib.GM_GROUP_N_TIMINGS))
+        return dict(zip(("cut_ms", "submit_ms", "device_ms", "merge_ms", "total_ms"), (float(x) for x in t)))
+
+    def edges(self):
+        """(slab edges [n_ranks + 1], whether they lie on planes of the VoxelGrid lattice)."""
+        e = (C.c_double * (len(self) + 1))()
+        on = C.c_uint32(0)
+        self._check(self._L.gm_group_get_edges(self._grp, e, len(self) + 1, C.byref(on)))
+        return np.array(e[:]), bool(on.value)
+
+    # ---- streaming: whole frames round-robin over the devices
+    def submit_frame(self, cloud):
+        c, keep = cloud if (isinstance(cloud, tuple) and isinstance(cloud[0], Cloud)) else GeometricMapping._cloud_from_xyz(cloud)
+        self._check(self._L.gm_group_submit_frame(self._grp, C.byref(c)))
+
+    def wait_frame(self):
+        """The oldest frame in flight: (result, rank, slot)."""
+        res = FrameResult()
+        rank, slot = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._L.gm_group_wait_frame(self._grp, C.byref(res), C.byref(rank), C.byref(slot)))
+        return GeometricMapping._result(res), int(rank.value), int(slot.value)
+
+    def in_flight(self):
+        return int(self._L.gm_group_in_flight(self._grp))
+
+    def rank_fetch(self, rank, slot, what):
+        """Bulky output of a streamed frame: what in {"cropped_xyz", "normals", "voxel_centroids"} -> float32 [n,4]."""
+        fn = getattr(self._L, "gm_get_" + what)
+        ctx = self._L.gm_group_ctx(self._grp, rank)
+        n = C.c_uint32(0)
+        st = fn(ctx, slot, None, 0, C.byref(n))
+        if st not in (GM_OK, GM_ERR_CAPACITY):
+            raise GmError(st, self._L.gm_last_error(ctx).decode())
         out = np.empty((n.value, 4), dtype=np.float32)
         if n.value:
-            self._check(self._L.gm_group_get_cropped_xyz(self._grp, _f32(out), n.value, C.byref(n)))
-        return out[:, :3].copy(), out[:, 3].copy().view(np.int32)
+            st = fn(ctx, slot, _f32(out), n.value, C.byref(n))
+            if st != GM_OK:
+                raise GmError(st, self._L.gm_last_error(ctx).decode())
+        return out
 
 
 def solve_local_frame(scatter6):

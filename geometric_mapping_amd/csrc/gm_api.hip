@@ -553,6 +553,15 @@ gm_status begin_stage(gm_ctx *ctx, Slot *&sl)
 namespace gm {
 
 gm_status gm_fail(gm_ctx *ctx, gm_status st, const char *msg) { return fail(ctx, st, msg); }
+VoxDense gm_make_vox_dense(const gm_ctx *ctx, uint32_t n_cap)
+{
+    const float lo = (float)(-ctx->cfg.boxFilterBound), hi = (float)ctx->cfg.boxFilterBound;
+    VoxDense vd;
+    memset(&vd, 0, sizeof(vd));
+    if ((ctx->cfg.flags & GM_CFG_VOXEL_GRID) && !ctx->force_voxel_sort)
+        vd = make_vox_dense(lo, hi, ctx->cfg.voxelGridLeafSize, n_cap, ctx->own_lo, ctx->own_hi);
+    return vd;
+}
 gm_status gm_ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, bool need_raw)
 {
     return ensure_capacity(ctx, sl, n, raw_bytes, need_raw);

@@ -200,6 +200,7 @@ void launch_nearest(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, co
 
 // gm_api.hip helpers shared with gm_ext.hip
 gm_status gm_fail(gm_ctx *ctx, gm_status st, const char *msg);
+VoxDense gm_make_vox_dense(const gm_ctx *ctx, uint32_t n_cap);   // the dense voxel table a frame of this context uses (enabled = 0: sort path)
 gm_status gm_ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, bool need_raw);
 gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H);
 gm_status gm_begin_stage(gm_ctx *ctx, Slot *&sl);

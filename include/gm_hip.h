@@ -286,19 +286,28 @@ typedef struct gm_map_primitive {
 gm_status gm_get_compressed_map(gm_ctx *ctx, uint32_t slot, void *buf, size_t capacity, size_t *n_bytes);
 
 /* ---- multi-device group: one host thread, every local GPU ---------------------
- * The reference is one single-threaded process (ros::spin(), src/geometric_mapping.cpp:169) on one CPU core; it has
- * no counterpart for this section.  north_star: "Frames shard spatially across the 8 GPUs of one node with an RCCL
- * all-gather of fitted primitives over xGMI only when a scan exceeds single-GPU capacity".
+ * The reference is one single-threaded process (ros::spin(), src/geometric_mapping.cpp:146,169: subscriber queue 1, one
+ * frame at a time) on one CPU core; it has no counterpart for this section.  north_star: "Frames shard spatially across
+ * the 8 GPUs of one node with an RCCL all-gather of fitted primitives over xGMI only when a scan exceeds single-GPU
+ * capacity"; BASELINE configs[3] (one frame over 4 GPUs) and configs[4] (frames streamed over 8 GPUs).
  *
  * A group owns one gm_ctx per rank (one rank per device) and, across distinct devices, one RCCL communicator per rank
- * (ncclCommInitAll, single process; librccl is loaded at run time).  gm_group_process_frame cuts ONE frame into
- * x-slabs balanced by the count of in-box points, adds a 1.01 * neighborRadius halo (neighbours only, never outputs:
- * gm_set_owned_range) ON THE HOST before H2D, runs the unchanged single-GPU pipeline on every rank asynchronously, and
- * exchanges the results with ONE ncclAllGather of a 24-double record per rank (scatter partials, counts, the rank's
- * fitted plane / cylinder).  The merged frame: scatter = sum of the partials (rank order), 3x3 solve, counts summed,
- * voxels re-joined across slab edges; fitted primitives by vote -- every rank's fit is a candidate, every rank counts
- * every candidate's inliers on its own resident owned points (gm_score_frame), the largest total wins.
- * Frames that fit one GPU need no group: stream them round-robin over per-device contexts (gm_submit_frame). */
+ * (ncclCommInitAll, single process; librccl is loaded at run time, the copy the process already has if it has one).
+ *
+ * SHARDED FRAME.  gm_group_process_frame cuts ONE frame into x-slabs balanced by the count of in-box points, adds a
+ * 1.01 * neighborRadius halo (neighbours only, never outputs: gm_set_owned_range) ON THE HOST before H2D -- one parallel
+ * pass for a histogram of x over the VoxelGrid lattice, edges on lattice planes (exactly, by the kernels' own float
+ * expression) so that no voxel straddles two ranks, one parallel pass that scatters the rows into per-rank page-locked
+ * buffers -- runs the unchanged single-GPU pipeline on every rank asynchronously, and exchanges the results with ONE
+ * ncclAllGather of a 24-double record per rank (scatter partials, counts, the rank's fitted plane / cylinder).  The
+ * merged frame: scatter = sum of the partials (rank order), 3x3 solve, counts summed, voxel centroids of the ranks in
+ * ascending pcl key order (bit for bit the unsharded frame's; a lattice too coarse to cut along is merged through the
+ * ranks' exact fixed-point voxel sums instead); fitted primitives by vote -- every rank's fit is a candidate, every rank
+ * counts every candidate's inliers on its own resident owned points (gm_score_frame), the largest total wins.
+ *
+ * STREAMING.  Frames that fit one GPU are independent: gm_group_submit_frame hands a whole frame to the next device in
+ * turn (its next free slot; gm_config.n_slots frames in flight per device), gm_group_wait_frame returns the frames in
+ * submission order.  No collective.  Results are those of gm_process_frame on that device, bit for bit. */
 typedef struct gm_group gm_group; /* opaque */
 #define GM_GROUP_LOOPBACK (1u << 0) /* ranks may share a device (tests on a 1-GPU box): the records travel by device
                                        copies instead of RCCL; everything else is the same code */
@@ -309,10 +318,37 @@ uint32_t gm_group_size(const gm_group *grp);
 gm_ctx *gm_group_ctx(gm_group *grp, uint32_t rank);
 const char *gm_group_last_error(const gm_group *grp); /* grp may be NULL for a failure inside gm_group_create */
 /* One sharded frame, blocking.  cloud must be host rows.  res: the merged frame (n_cropped counts every in-box point
- * once; eigen results from the summed scatter; plane / cylinder = the vote's winners with their global inlier counts). */
+ * once; eigen results from the summed scatter; plane / cylinder = the vote's winners with their global inlier counts).
+ * After a failure nothing of the frame is in flight and the accessors below report GM_ERR_NOT_READY; after a failed
+ * collective (GM_ERR_COMM) the group refuses further work. */
 gm_status gm_group_process_frame(gm_group *grp, const gm_cloud *cloud, gm_frame_result *res);
 /* /choppedCloud of the last sharded frame in the single-GPU order (ascending input row); rows x,y,z,pad(= input row) */
 gm_status gm_group_get_cropped_xyz(gm_group *grp, float *xyzw, uint32_t capacity, uint32_t *n_out);
+/* pcl::VoxelGrid output of the last sharded frame, ascending key order: rows x,y,z,count (src/tunnel_processing.cpp:217-220) */
+gm_status gm_group_get_voxel_centroids(gm_group *grp, float *xyzc, uint32_t capacity, uint32_t *n_out);
+/* per centroid: nx,ny,nz,curvature of its nearest valid point / that point's index in gm_group_get_cropped_xyz's order
+ * (kdtree->nearestKSearch + normals->at of the marker loop, src/tunnel_processing.cpp:237-249); the search runs on every
+ * rank, the closest point of all wins.  Needs GM_CFG_NEAREST | GM_CFG_VOXEL_GRID. */
+gm_status gm_group_get_voxel_normals(gm_group *grp, float *nxyzc, uint32_t capacity, uint32_t *n_out);
+gm_status gm_group_get_voxel_nearest(gm_group *grp, int32_t *idx, uint32_t capacity, uint32_t *n_out);
+/* wall-clock split of the last gm_group_process_frame call, milliseconds */
+enum { GM_GROUP_T_CUT = 0,    /* host: histogram, edges, rows scattered into the per-rank page-locked buffers */
+       GM_GROUP_T_SUBMIT = 1, /* host: the ranks' frames enqueued (H2D + launch chains) */
+       GM_GROUP_T_DEVICE = 2, /* waiting for H2D, kernels and the all-gather of every rank */
+       GM_GROUP_T_MERGE = 3,  /* records merged, voxel lists merged, primitive vote */
+       GM_GROUP_T_TOTAL = 4,
+       GM_GROUP_N_TIMINGS = 5 };
+gm_status gm_group_get_timing(const gm_group *grp, double *ms, uint32_t capacity);
+/* the n_ranks + 1 slab edges of the last sharded frame (first -inf, last +inf); *on_lattice = 1 when they lie on planes
+ * of the VoxelGrid lattice */
+gm_status gm_group_get_edges(const gm_group *grp, double *edges, uint32_t capacity, uint32_t *on_lattice);
+/* streaming: a whole frame to the next device in turn, asynchronously (cloud as for gm_submit_frame: host rows are
+ * released on return unless GM_CLOUD_PINNED); GM_ERR_NOT_READY when every slot of every device holds a frame */
+gm_status gm_group_submit_frame(gm_group *grp, const gm_cloud *cloud);
+/* the oldest frame in flight (submission order); *rank / *slot (may be NULL) name where its bulky outputs can be fetched
+ * (gm_get_cropped_xyz(gm_group_ctx(grp, rank), slot, ...)) until that slot is submitted to again */
+gm_status gm_group_wait_frame(gm_group *grp, gm_frame_result *res, uint32_t *rank, uint32_t *slot);
+uint32_t gm_group_in_flight(const gm_group *grp);
 
 #ifdef __cplusplus
 }
