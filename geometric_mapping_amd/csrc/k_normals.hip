@@ -1617,6 +1617,8 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     const uint64_t ncell = (uint64_t)g.nx * g.ny * g.nz;
     int bits = 1;
     while ((1ull << bits) < ncell) ++bits;
+    // (moving the cropped rows into sorted order inside the sort's last pass, which knows every item's final place, was
+    // measured: its scattered 16-byte row writes cost the pass 13 us, the gather blocks of k_rows_and_tiles below cost 8)
     const int where = launch_radix_sort(sl.keys_a, sl.vals_a, sl.keys_b, sl.vals_b, &sl.ctr->n_cropped, n_cap, bits,
                                         sl.sort, scratch_cleared, s);
     uint32_t *skeys = where ? sl.keys_b : sl.keys_a;

@@ -334,29 +334,31 @@ __global__ __launch_bounds__(kScThreads) void k_score(const float4 *__restrict__
                                                       const uint32_t *__restrict__ n_ptr, uint32_t n_host,
                                                       const float *__restrict__ hyp8,
                                                       const float2 *__restrict__ band, uint32_t H, float tau,
-                                                      uint32_t stride, int32_t *__restrict__ counts, SelectNext nx)
+                                                      uint32_t stride, uint32_t tile, int32_t *__restrict__ counts, SelectNext nx)
 {
     extern __shared__ unsigned long long sel_keys[];
     // points in LDS as groups of four, SoA inside a group: x0..x3 | y0..y3 | z0..z3, so three
     // broadcast ds_read_b128 deliver four points
     __shared__ float4 lp[kScTile / 4][3];
     // with stride > 1 only every stride-th point is scored (the pre-selection stage of the in-frame RANSAC)
+    // tile (<= kScTile, a multiple of 4): points per block.  A pre-selection stage sees a few thousand points: small tiles
+    // spread them over every CU instead of a long loop on a fifth of them.
     const uint32_t n_full = n_ptr ? *n_ptr : n_host;
     const uint32_t n = (n_full + stride - 1) / stride;
-    const uint32_t base = blockIdx.x * kScTile;
+    const uint32_t base = blockIdx.x * tile;
     if (base < n) {  // uniform per block
-    const uint32_t m = (n - base < (uint32_t)kScTile) ? n - base : (uint32_t)kScTile;
+    const uint32_t m = (n - base < tile) ? n - base : tile;
     const uint32_t groups = (m + 3u) >> 2;
 #pragma unroll
     for (int p = 0; p < kScP; ++p) {
         const uint32_t j = p * kScThreads + threadIdx.x;
         const uint32_t i = (base + j) * stride;
-        bool ok = base + j < n;
+        bool ok = j < m;
         if (ok && labels) ok = labels[i] == want;
         float4 v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 0.f);
         if (ok) v = pts[i];  // masked / out-of-range points are NaN: never an inlier
         float *g = reinterpret_cast<float *>(&lp[j >> 2][0]);
-        g[(j & 3)] = v.x; g[4 + (j & 3)] = v.y; g[8 + (j & 3)] = v.z;
+        if (j < ((m + 3u) & ~3u)) { g[(j & 3)] = v.x; g[4 + (j & 3)] = v.y; g[8 + (j & 3)] = v.z; }
     }
     float hp[kScHPL][8];
     float c[kScHPL];  // float counters (exact: <= kScTile per block): keeps the compiler on cmp+cndmask+add
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(256) void k_select_topk(const int32_t *__restrict__
 // hypothesis (in registers; blockIdx.y picks the chunk of 64), each of the block's 4 waves owns 256 points staged
 // in LDS as SoA groups of four, pure-VALU inner loop, LDS reduce over the waves, one integer atomicAdd per
 // (block, hypothesis).
-template <int MODEL>
+template <int MODEL, int PTS /* points per wave: 256, or 64 to spread a small stage over the chip */>
 __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pts, const uint8_t *__restrict__ labels,
                                                    uint32_t want, const uint32_t *__restrict__ n_ptr, uint32_t n_host,
                                                    const float *__restrict__ hyp8, const float2 *__restrict__ band,
@@ -481,7 +483,6 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
                                                    uint32_t stride, int32_t *__restrict__ counts_k, SelectNext nx)
 {
     extern __shared__ unsigned long long sel_keys[];
-    constexpr int PTS = 256;  // per wave
     __shared__ float4 lp[4][PTS / 4][3];
     __shared__ float red[4][64];
     const uint32_t n_full = n_ptr ? *n_ptr : n_host;
@@ -799,11 +800,11 @@ void launch_score(int model, const float4 *pts, const uint8_t *labels, uint32_t 
     hipMemsetAsync(counts, 0, sizeof(int32_t) * H, s);
     if (model == 0) {
         hipLaunchKernelGGL(k_score<0>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
-                           (const float2 *)band, H, (float)tau, 1u, counts, SelectNext{});
+                           (const float2 *)band, H, (float)tau, 1u, (uint32_t)kScTile, counts, SelectNext{});
     } else {
         hipLaunchKernelGGL(k_cyl_bands, dim3((H + 255) / 256), dim3(256), 0, s, hyp8, H, tau, band);
         hipLaunchKernelGGL(k_score<1>, grid, dim3(kScThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8,
-                           (const float2 *)band, H, (float)tau, 1u, counts, SelectNext{});
+                           (const float2 *)band, H, (float)tau, 1u, (uint32_t)kScTile, counts, SelectNext{});
     }
     hipLaunchKernelGGL(k_best_hypothesis, dim3(1), dim3(1024), 0, s, (const int32_t *)counts, H, best);
 }
@@ -819,10 +820,16 @@ static void score_stage_all(const float4 *pts, const uint8_t *labels, uint32_t w
                             int32_t *counts, const SelectNext &next, hipStream_t s)
 {
     const uint32_t n_sub = (n_cap + stride - 1) / stride;
-    const uint32_t nb = score_blocks(n_sub) ? score_blocks(n_sub) : 1;
-    hipLaunchKernelGGL(k_score<MODEL>, dim3(nb, (H + kScHC - 1) / kScHC), dim3(kScThreads),
+    // points per block: as few as keep ~2 blocks per CU busy (at least 32: a block's fixed costs), at most kScTile
+    const uint32_t hy = (H + kScHC - 1) / kScHC;
+    uint32_t tile = (uint32_t)kScTile;
+    while (tile > 32u && (uint64_t)((n_sub + tile - 1) / tile) * hy < 512u) tile >>= 1;
+    static const char *te = getenv("GM_RANSAC_TILE");   // experiments
+    if (te) tile = (uint32_t)atoi(te);
+    const uint32_t nb = (n_sub + tile - 1) / tile ? (n_sub + tile - 1) / tile : 1;
+    hipLaunchKernelGGL(k_score<MODEL>, dim3(nb, hy), dim3(kScThreads),
                        next.sel ? select_lds_bytes(next.M) : 0u, s, pts, labels, want, n_ptr, n_cap, hyp8, band, H,
-                       (float)tau, stride, counts, next);
+                       (float)tau, stride, tile, counts, next);
 }
 template <int MODEL>
 static void score_stage_sel(const float4 *pts, const uint8_t *labels, uint32_t want, const uint32_t *n_ptr, uint32_t n_cap,
@@ -830,9 +837,18 @@ static void score_stage_sel(const float4 *pts, const uint8_t *labels, uint32_t w
                             uint32_t stride, int32_t *counts_k, const SelectNext &next, hipStream_t s)
 {
     const uint32_t n_sub = (n_cap + stride - 1) / stride;
-    const uint32_t nb = (n_sub + 1023) / 1024 ? (n_sub + 1023) / 1024 : 1;
-    hipLaunchKernelGGL(k_score_sel<MODEL>, dim3(nb, (K + 63) / 64), dim3(256), next.sel ? select_lds_bytes(next.M) : 0u, s,
-                       pts, labels, want, n_ptr, n_cap, hyp8, band, sel, K, (float)tau, stride, counts_k, next);
+    const uint32_t ky = (K + 63) / 64;
+    // (K <= 32 splits a wave's points over lane parts and wants the full 256; otherwise 64 points per wave when the stage
+    // would not fill the chip with 256)
+    const bool small = K > 32u && (uint64_t)((n_sub + 1023) / 1024) * ky < 512u;
+    const uint32_t per_block = small ? 256u : 1024u;
+    const uint32_t nb = (n_sub + per_block - 1) / per_block ? (n_sub + per_block - 1) / per_block : 1;
+    if (small)
+        hipLaunchKernelGGL((k_score_sel<MODEL, 64>), dim3(nb, ky), dim3(256), next.sel ? select_lds_bytes(next.M) : 0u, s,
+                           pts, labels, want, n_ptr, n_cap, hyp8, band, sel, K, (float)tau, stride, counts_k, next);
+    else
+        hipLaunchKernelGGL((k_score_sel<MODEL, 256>), dim3(nb, ky), dim3(256), next.sel ? select_lds_bytes(next.M) : 0u, s,
+                           pts, labels, want, n_ptr, n_cap, hyp8, band, sel, K, (float)tau, stride, counts_k, next);
 }
 static void select_topk(const int32_t *counts, const uint32_t *ids, uint32_t M, uint32_t K, uint32_t *sel,
                         int32_t *counts_out, hipStream_t s)
