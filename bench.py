@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--graph", type=int, default=0, help="1: the timed contexts replay their launch chains from captured hipGraphs (GM_CFG_GRAPH)")
     ap.add_argument("--frames", type=int, default=24, help="frames of the per-frame (blocking, H2D-inclusive) protocol")
     ap.add_argument("--profile-tag", default=None, help="rNN prefix of the profiles/ files to quote (default: newest)")
+    ap.add_argument("--group-points", type=int, default=10_000_000,
+                    help="points of the sharded-frame row (gm_group, 4 ranks sharing this GPU: BASELINE configs[3] shape); 0: skip")
     return ap.parse_args()
 
 
@@ -394,6 +396,28 @@ def main():
             secondary["stress_launch_literal"] = {"neighborRadius": 0.5, "k_regime": "launch-literal (~5 100 neighbours)",
                                                   "normals_kernel_ms": float(np.median(km)), "frame_ms": float(np.median(ms)),
                                                   "points_per_s": n / (float(np.median(ms)) * 1e-3), "input": "rows resident in HBM"}
+
+        # ---- one frame sharded over 4 ranks inside the C ABI (gm_group; the ranks share this GPU, so the records travel by
+        # device copies and the four slabs' kernels queue on one device): where the time of gm_group_process_frame goes
+        if args.group_points:
+            gn = args.group_points
+            gx = synth.tunnel_frame(gn, seed=3, floor_z=-1.2, outlier_frac=0.01)
+            with g.GeometricMappingGroup([local_rank] * 4, loopback=True, boxFilterBound=bound, voxelGridLeafSize=leaf,
+                                         neighborRadius=synth.fixed_k_radius(gn), weightingFactor=wf,
+                                         flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_RANSAC_PLANE | _lib.GM_CFG_RANSAC_CYLINDER,
+                                         ransac_hypotheses=1024, ransac_threshold=0.03, ransac_seed=5) as gg:
+                gg.process_frame(gx)
+                ts = []
+                for _ in range(3):
+                    gg.process_frame(gx)
+                    ts.append(gg.timing())
+                edges, on_lattice = gg.edges()
+            secondary["group_sharded_frame"] = {
+                "points": gn, "ranks": 4, "transport": "loopback (4 ranks on one GPU; RCCL needs distinct devices)",
+                "edges_on_voxel_lattice": on_lattice, "host_threads": min(16, usable_cpus()),
+                **{k: round(float(np.median([t[k] for t in ts])), 3) for k in ts[0]},
+                "note": "cut_ms = host: x histogram over the voxel lattice, edges, rows scattered into per-rank page-locked "
+                        "buffers; device_ms = H2D + the four slabs' kernels one after the other on this one GPU + gather"}
 
     # dominant kernel: the neighbourhood-normals kernel, HIP-event bracketed on the stream it runs on
     # (gm_frame_result.normals_kernel_ms): in the timed region it shares the chip with the other frames in flight,

@@ -66,7 +66,7 @@ static bool radius_ok(double r) { return std::isfinite(r) && (r == 0.0 || (r >= 
 // overrides; only the matrix-core kernel knows D > 1.
 static int rows_per_radius(double radius, float ex, float ey, float ez, uint32_t n_points)
 {
-    static const char *e = getenv("GM_NORMALS_ROWS");
+    const char *e = getenv("GM_NORMALS_ROWS");          // (read per context: tests switch it between cases)
     static const char *impl = getenv("GM_NORMALS_IMPL");
     if (impl && !(impl[0] == 'a' || impl[0] == 'm') ) return 1;
     if (impl && strchr(impl, '0')) return 1;
@@ -390,14 +390,14 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     record(ctx, sl, 0);
     const uint8_t *dev_rows = (const uint8_t *)cloud->data;
     if (!on_dev && n) {
-        // Page-locked rows (gm_host_alloc) are mapped into the device's address space.  In a BLOCKING call the crop kernel
-        // reads them where they are, over PCIe at the rate a copy would run at: the copy -- a serial prefix of the frame,
-        // nothing else can start before the crop has seen every row -- is gone together with its hand-over to the first
-        // kernel (0.72 -> 0.68 ms for the 1 M-point frame).  Not for gm_submit_frame: with frames in flight the copy
-        // engines move the next frame's rows beside the kernels, while a crop kernel that waits on PCIe holds the CUs the
-        // other frames' kernels want (measured: 0.40 -> 0.52 ms per step).
-        static const char *zc = getenv("GM_PINNED_ZERO_COPY");   // 0: always copy first / 2: never copy (A/B measurements)
-        const int zmode = zc ? atoi(zc) : 1;
+        // Page-locked rows (gm_host_alloc) are mapped into the device's address space, so the crop kernel COULD read them
+        // where they are, over PCIe, instead of waiting for a copy (GM_PINNED_ZERO_COPY=1: blocking calls only, =2: every
+        // call).  Measured on the 1 M-point frame: a blocking frame 0.697 -> 0.679 ms, but with frames in flight a crop
+        // kernel that waits on PCIe holds the CUs the other frames' kernels want (0.35 -> 0.52 ms per step), and once a
+        // kernel has read a page-locked buffer later copies FROM that buffer run a quarter slower (0.35 -> 0.49 ms per
+        // step).  Off by default.
+        static const char *zc = getenv("GM_PINNED_ZERO_COPY");
+        const int zmode = zc ? atoi(zc) : 0;
         void *mapped = nullptr;
         if ((cloud->flags & GM_CLOUD_PINNED) && (zmode == 2 || (zmode == 1 && blocking_call)) &&
             hipHostGetDevicePointer(&mapped, const_cast<void *>(cloud->data), 0) == hipSuccess && mapped) {

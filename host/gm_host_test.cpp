@@ -89,6 +89,27 @@ int main(int argc, char **argv)
             Marker untouched;
             REQUIRE(!Processor::rvizCylinder(none, 10.0, untouched));
         }
+        // --- streaming through the device-list constructor (gm_group_submit_frame / gm_group_wait_frame): frames come
+        // back in submission order, each the frame processFrame computes, and the accessors follow the returned frame
+        {
+            std::vector<int> devs(1, 0);
+            Processor ps(5.0, 0.5, 0.5, 0.2, devs, GM_CFG_DEFAULT, 2);
+            REQUIRE(ps.capacity() == 2 && ps.inFlight() == 0);
+            const unsigned sizes[4] = {(unsigned)n, (unsigned)(n / 2), (unsigned)(n / 3), (unsigned)n};
+            unsigned done = 0;
+            for (int k = 0; k < 4 || ps.inFlight(); ) {
+                while (k < 4 && ps.inFlight() < ps.capacity()) { ps.submitFrame(&rows[0], sizes[k], step, 0, 4, 8); ++k; }
+                gm_frame_result rs = ps.waitFrame();
+                REQUIRE(rs.n_in == sizes[done]);
+                REQUIRE(ps.choppedCloud().size() == rs.n_valid);
+                if (sizes[done] == (unsigned)n) {
+                    REQUIRE(rs.n_valid == r.n_valid && std::memcmp(rs.scatter, r.scatter, sizeof(r.scatter)) == 0);
+                    REQUIRE(std::memcmp(&ps.choppedCloud()[0], &chopped[0], chopped.size() * sizeof(PointXYZ)) == 0);
+                }
+                ++done;
+            }
+            REQUIRE(done == 4);
+        }
         // error conventions: a status, never a crash
         bool threw = false;
         try { proc.getLocalFrame((int)cloudNormals.size() + 1, 0.2, cloudNormals, eigenVals, eigenVecs); } catch (const std::out_of_range &) { threw = true; }

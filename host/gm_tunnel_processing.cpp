@@ -11,7 +11,8 @@ void Processor::check(gm_status s, const char *what)
     if (s != GM_OK) throw Error(s, std::string(what) + ": " + gm_status_string(s) + ": " + gm_last_error(ctx_));
 }
 
-Processor::Processor(double b, double leaf, double r, double wf, int device, unsigned flags) : ctx_(0)
+Processor::Processor(double b, double leaf, double r, double wf, int device, unsigned flags)
+    : ctx_(0), grp_(0), cur_(0), cur_slot_(0), n_slots_(1), next_slot_(0), pending_(0)
 {
     gm_config cfg;
     gm_default_config(&cfg);
@@ -19,9 +20,66 @@ Processor::Processor(double b, double leaf, double r, double wf, int device, uns
     cfg.device = device; cfg.flags = flags;
     gm_status s = gm_create(&cfg, &ctx_);
     if (s != GM_OK) throw Error(s, std::string("gm_create: ") + gm_last_error(0));
+    cur_ = ctx_;
 }
 
-Processor::~Processor() { gm_destroy(ctx_); }
+Processor::Processor(double b, double leaf, double r, double wf, const std::vector<int> &devices, unsigned flags,
+                     unsigned slots_per_device)
+    : ctx_(0), grp_(0), cur_(0), cur_slot_(0), n_slots_(slots_per_device ? slots_per_device : 1), next_slot_(0), pending_(0)
+{
+    if (devices.empty()) throw Error(GM_ERR_INVALID_ARG, "Processor: empty device list");
+    gm_config cfg;
+    gm_default_config(&cfg);
+    cfg.boxFilterBound = b; cfg.voxelGridLeafSize = leaf; cfg.neighborRadius = r; cfg.weightingFactor = wf;
+    cfg.flags = flags; cfg.n_slots = n_slots_;
+    std::vector<int32_t> dev(devices.begin(), devices.end());
+    gm_status s = gm_group_create(&cfg, &dev[0], (uint32_t)dev.size(), 0u, &grp_);
+    if (s != GM_OK) throw Error(s, std::string("gm_group_create: ") + gm_group_last_error(0));
+    ctx_ = gm_group_ctx(grp_, 0);
+    cur_ = ctx_;
+}
+
+Processor::~Processor()
+{
+    if (grp_) gm_group_destroy(grp_);   // (owns the contexts)
+    else gm_destroy(ctx_);
+}
+
+unsigned Processor::capacity() const { return grp_ ? gm_group_size(grp_) * n_slots_ : n_slots_; }
+unsigned Processor::inFlight() const { return grp_ ? gm_group_in_flight(grp_) : pending_; }
+
+void Processor::submitFrame(const void *rows, unsigned n, unsigned step, unsigned ox, unsigned oy, unsigned oz, bool bigendian)
+{
+    gm_cloud c = {rows, n, step, ox, oy, oz, bigendian ? GM_CLOUD_BIGENDIAN : 0u};
+    if (grp_) {
+        gm_status s = gm_group_submit_frame(grp_, &c);
+        if (s != GM_OK) throw Error(s, std::string("submitFrame: ") + gm_group_last_error(grp_));
+        return;
+    }
+    if (pending_ >= n_slots_) throw Error(GM_ERR_NOT_READY, "submitFrame: every slot holds a frame (waitFrame first)");
+    check(gm_submit_frame(ctx_, next_slot_, &c), "submitFrame");
+    next_slot_ = (next_slot_ + 1) % n_slots_;
+    ++pending_;
+}
+
+gm_frame_result Processor::waitFrame()
+{
+    gm_frame_result r;
+    if (grp_) {
+        uint32_t rank = 0, slot = 0;
+        gm_status s = gm_group_wait_frame(grp_, &r, &rank, &slot);
+        if (s != GM_OK) throw Error(s, std::string("waitFrame: ") + gm_group_last_error(grp_));
+        cur_ = gm_group_ctx(grp_, rank);
+        cur_slot_ = slot;
+        return r;
+    }
+    if (!pending_) throw Error(GM_ERR_NOT_READY, "waitFrame: no frame in flight");
+    const unsigned slot = (next_slot_ + n_slots_ - pending_) % n_slots_;   // the oldest
+    check(gm_wait_frame(ctx_, slot, &r), "waitFrame");
+    --pending_;
+    cur_ = ctx_; cur_slot_ = slot;
+    return r;
+}
 
 PointCloud Processor::chopCloud(const double &bound, const PointCloud &cloud)
 {
@@ -82,19 +140,25 @@ std::vector<int> Processor::nearest(const PointCloud &cloud, const PointCloud &q
 gm_frame_result Processor::processFrame(const void *rows, unsigned n, unsigned step, unsigned ox, unsigned oy, unsigned oz,
                                         bool bigendian)
 {
+    if (grp_ || pending_) {   // (frames already in flight finish first: results come back in submission order)
+        while (inFlight()) waitFrame();
+        submitFrame(rows, n, step, ox, oy, oz, bigendian);
+        return waitFrame();
+    }
     gm_cloud c = {rows, n, step, ox, oy, oz, bigendian ? GM_CLOUD_BIGENDIAN : 0u};
     gm_frame_result r;
     check(gm_process_frame(ctx_, &c, &r), "processFrame");
+    cur_ = ctx_; cur_slot_ = 0;
     return r;
 }
 
 PointCloud Processor::choppedCloud()
 {
     uint32_t n = 0;
-    gm_status s = gm_get_cropped_xyz(ctx_, 0, 0, 0, &n);
+    gm_status s = gm_get_cropped_xyz(cur_, cur_slot_, 0, 0, &n);
     if (s != GM_OK && s != GM_ERR_CAPACITY) check(s, "choppedCloud");
     PointCloud out(n ? n : 1);
-    check(gm_get_cropped_xyz(ctx_, 0, &out[0].x, (uint32_t)out.size(), &n), "choppedCloud");
+    check(gm_get_cropped_xyz(cur_, cur_slot_, &out[0].x, (uint32_t)out.size(), &n), "choppedCloud");
     out.resize(n);
     return out;
 }
@@ -102,10 +166,10 @@ PointCloud Processor::choppedCloud()
 NormalCloud Processor::normals()
 {
     uint32_t n = 0;
-    gm_status s = gm_get_normals(ctx_, 0, 0, 0, &n);
+    gm_status s = gm_get_normals(cur_, cur_slot_, 0, 0, &n);
     if (s != GM_OK && s != GM_ERR_CAPACITY) check(s, "normals");
     NormalCloud out(n ? n : 1);
-    check(gm_get_normals(ctx_, 0, &out[0].normal[0], (uint32_t)out.size(), &n), "normals");
+    check(gm_get_normals(cur_, cur_slot_, &out[0].normal[0], (uint32_t)out.size(), &n), "normals");
     out.resize(n);
     return out;
 }
@@ -113,10 +177,10 @@ NormalCloud Processor::normals()
 PointCloud Processor::voxelCentroids()
 {
     uint32_t n = 0;
-    gm_status s = gm_get_voxel_centroids(ctx_, 0, 0, 0, &n);
+    gm_status s = gm_get_voxel_centroids(cur_, cur_slot_, 0, 0, &n);
     if (s != GM_OK && s != GM_ERR_CAPACITY) check(s, "voxelCentroids");
     PointCloud out(n ? n : 1);
-    check(gm_get_voxel_centroids(ctx_, 0, &out[0].x, (uint32_t)out.size(), &n), "voxelCentroids");
+    check(gm_get_voxel_centroids(cur_, cur_slot_, &out[0].x, (uint32_t)out.size(), &n), "voxelCentroids");
     out.resize(n);
     return out;
 }
@@ -124,10 +188,10 @@ PointCloud Processor::voxelCentroids()
 NormalCloud Processor::voxelNormals()
 {
     uint32_t n = 0;
-    gm_status s = gm_get_voxel_normals(ctx_, 0, 0, 0, &n);
+    gm_status s = gm_get_voxel_normals(cur_, cur_slot_, 0, 0, &n);
     if (s != GM_OK && s != GM_ERR_CAPACITY) check(s, "voxelNormals");
     NormalCloud out(n ? n : 1);
-    check(gm_get_voxel_normals(ctx_, 0, &out[0].normal[0], (uint32_t)out.size(), &n), "voxelNormals");
+    check(gm_get_voxel_normals(cur_, cur_slot_, &out[0].normal[0], (uint32_t)out.size(), &n), "voxelNormals");
     out.resize(n);
     return out;
 }

@@ -57,7 +57,20 @@ public:
     // names/defaults: include/geometric_mapping/paramHandler.hpp:26-29, launch/mapping.launch:7-10
     Processor(double boxFilterBound = 5.0, double voxelGridLeafSize = 0.5, double neighborRadius = 0.5,
               double weightingFactor = 0.2, int device = 0, unsigned flags = GM_CFG_DEFAULT);
+    // Several devices: frames are streamed round-robin over them (gm_group_submit_frame / gm_group_wait_frame,
+    // `slots_per_device` frames in flight on each) -- the reference's one-frame-at-a-time consumer
+    // (src/geometric_mapping.cpp:146,169) becomes a pipeline as deep as capacity().  processFrame() keeps working
+    // (submit + wait), the stage calls use the first device.
+    Processor(double boxFilterBound, double voxelGridLeafSize, double neighborRadius, double weightingFactor,
+              const std::vector<int> &devices, unsigned flags, unsigned slots_per_device = 2);
     ~Processor();
+
+    // ---- streaming (any constructor; with one device and one slot it degenerates to processFrame) ----
+    unsigned capacity() const;        // frames that can be in flight
+    unsigned inFlight() const;
+    void submitFrame(const void *rows, unsigned n_points, unsigned point_step, unsigned off_x, unsigned off_y, unsigned off_z,
+                     bool bigendian = false);   // the rows may be released on return
+    gm_frame_result waitFrame();      // the oldest frame in flight; the accessors below then refer to it
 
     // ---- tunnel_processing.hpp:38-54 ----
     PointCloud chopCloud(const double &bound, const PointCloud &cloud);
@@ -99,7 +112,11 @@ public:
 
 private:
     void check(gm_status s, const char *what);
-    gm_ctx *ctx_;
+    gm_ctx *ctx_;          // the context the stage calls run on (the group's first rank when there is a group)
+    gm_group *grp_;        // several devices: owns the contexts
+    gm_ctx *cur_;          // where the last completed frame's bulky outputs live ...
+    unsigned cur_slot_;    // ... and in which slot
+    unsigned n_slots_, next_slot_, pending_;   // single device: ring of slots
     Processor(const Processor &);
     Processor &operator=(const Processor &);
 };

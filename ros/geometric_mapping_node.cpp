@@ -27,13 +27,24 @@
 //     still indexes the pre-compaction cloud, src/tunnel_processing.cpp:65,85,239);
 //   * with displayNormals the context is created with GM_CFG_NEAREST: the voxel grid, the 1-NN and the gather of
 //     the nearest points' normals all happen inside the one frame pass, the node fetches V centroids + V normals.
+// Two parameters of its own, both off by default (the reference's launch file then behaves as before):
+//   gmGraphReplay  bool    replay the frame's launch chain from a captured hipGraph (GM_CFG_GRAPH).  Pays for clouds of
+//                          a steady size; a lidar whose point count wanders across 1/16-wide size buckets re-captures
+//                          (hipStreamBeginCapture + hipGraphInstantiate) inside the callback, so it is a choice
+//   gmDevices      string  "0,1,2,...": more than one device streams the frames round-robin over them
+//                          (gm_group_submit_frame / gm_group_wait_frame): the callback submits a frame and publishes the
+//                          oldest finished one once every device is busy -- a pipeline a few frames deep instead of
+//                          the one-frame-at-a-time consumer of src/geometric_mapping.cpp:146,169
 #include <ros/ros.h>
 #include <sensor_msgs/PointCloud2.h>
 #include <sensor_msgs/PointField.h>
 #include <visualization_msgs/MarkerArray.h>
 
+#include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "../host/gm_tunnel_processing.hpp"
@@ -43,6 +54,8 @@ namespace {
 struct Parameters {  // mirrors class Parameters, include/geometric_mapping/paramHandler.hpp:9-37
     double boxFilterBound = 5.0, leafSize = .1, neighborRadius = .03, weightingFactor = .2;
     bool rvizCloud = true, rvizNormals = true, rvizCenterAxis = true, pclviz = false, rvizCylinder = false;
+    bool graphReplay = false;          // gmGraphReplay
+    std::vector<int> devices;          // gmDevices (empty: device 0, one frame at a time)
     explicit Parameters(ros::NodeHandle &node)
     {
         // global names, read once (src/paramHandler.cpp:13-65); log text kept
@@ -59,11 +72,22 @@ struct Parameters {  // mirrors class Parameters, include/geometric_mapping/para
         node.getParam("displayCenterAxis", rvizCenterAxis);
         node.getParam("usePCLViz", pclviz);
         node.getParam("displayCylinder", rvizCylinder);
+        node.getParam("gmGraphReplay", graphReplay);
+        std::string dev;
+        if (node.getParam("gmDevices", dev)) {
+            for (size_t i = 0; i < dev.size();) {
+                size_t j = dev.find(',', i);
+                if (j == std::string::npos) j = dev.size();
+                if (j > i) devices.push_back(std::atoi(dev.substr(i, j - i).c_str()));
+                i = j + 1;
+            }
+        }
     }
 };
 
 std::unique_ptr<Parameters> params;
 std::unique_ptr<gm_host::Processor> proc;
+std::deque<std_msgs::Header> headers;   // of the frames in flight (streaming over several devices)
 ros::Publisher cloudPub, normalsPub, centerAxisPub, cylinderPub;
 
 bool find_xyz(const sensor_msgs::PointCloud2 &m, unsigned &ox, unsigned &oy, unsigned &oz)
@@ -127,7 +151,17 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input)
                             (size_t)input->width * input->point_step);
             rows = &packed[0];
         }
-        r = proc->processFrame(rows, n, input->point_step, ox, oy, oz, input->is_bigendian);
+        if (params->devices.size() > 1) {
+            // streaming: hand the frame to the next device; publish the oldest frame once the pipeline is full
+            proc->submitFrame(rows, n, input->point_step, ox, oy, oz, input->is_bigendian);
+            headers.push_back(input->header);
+            if (proc->inFlight() < proc->capacity()) return;
+            r = proc->waitFrame();
+        } else {
+            r = proc->processFrame(rows, n, input->point_step, ox, oy, oz, input->is_bigendian);
+            headers.clear();
+            headers.push_back(input->header);
+        }
     } catch (const gm_host::Error &e) {
         ROS_ERROR("libgm_hip: %s", e.what());
         return;
@@ -142,7 +176,7 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input)
     if (params->rvizCloud) {  // :100-107, xyz-only PointCloud2 as pcl::toROSMsg lays it out (16-byte points)
         const gm_host::PointCloud cloud = proc->choppedCloud();
         sensor_msgs::PointCloud2 out;
-        out.header = input->header;
+        out.header = headers.front();   // (the frame being published: the oldest in flight)
         out.height = 1; out.width = (uint32_t)cloud.size();
         out.is_bigendian = false; out.is_dense = true;
         out.point_step = 16; out.row_step = 16 * out.width;
@@ -164,6 +198,7 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input)
         gm_host::Marker cyl;
         if (gm_host::Processor::rvizCylinder(r, 2.0 * params->boxFilterBound, cyl)) cylinderPub.publish(to_ros(cyl));
     }
+    headers.pop_front();
     ROS_INFO("Published...");
 }
 
@@ -177,11 +212,14 @@ int main(int argc, char **argv)
     ROS_INFO("Launched geometric_mapping_node...");
     if (params->pclviz) ROS_WARN("usePCLViz is ignored by the MI355X host (no PCL in this build)");
     try {
-        proc.reset(new gm_host::Processor(params->boxFilterBound, params->leafSize, params->neighborRadius,
-                                          params->weightingFactor, 0,
-                                          GM_CFG_DEFAULT | (params->rvizCylinder ? GM_CFG_RANSAC_CYLINDER : 0u) |
-                                              (params->rvizNormals ? GM_CFG_NEAREST : 0u) |
-                                              GM_CFG_GRAPH));   // one frame at a time: replay the launch chain
+        const unsigned flags = GM_CFG_DEFAULT | (params->rvizCylinder ? GM_CFG_RANSAC_CYLINDER : 0u) |
+                               (params->rvizNormals ? GM_CFG_NEAREST : 0u) | (params->graphReplay ? GM_CFG_GRAPH : 0u);
+        if (params->devices.size() > 1)
+            proc.reset(new gm_host::Processor(params->boxFilterBound, params->leafSize, params->neighborRadius,
+                                              params->weightingFactor, params->devices, flags, 2));
+        else
+            proc.reset(new gm_host::Processor(params->boxFilterBound, params->leafSize, params->neighborRadius,
+                                              params->weightingFactor, params->devices.empty() ? 0 : params->devices[0], flags));
     } catch (const gm_host::Error &e) {
         ROS_FATAL("libgm_hip: %s", e.what());
         return 1;

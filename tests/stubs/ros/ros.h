@@ -15,6 +15,7 @@ class NodeHandle {
 public:
     bool getParam(const std::string &, double &) const { return false; }
     bool getParam(const std::string &, bool &) const { return false; }
+    bool getParam(const std::string &, std::string &) const { return false; }
     template <class M> Publisher advertise(const std::string &, uint32_t) { return Publisher(); }
     template <class M> Subscriber subscribe(const std::string &, uint32_t, void (*)(const gm_stub::shared_ptr<M const> &)) { return Subscriber(); }
 };

@@ -42,14 +42,24 @@ def make_cloud(rng, kind, n):
 
 import os
 
-# (GM_FUZZ_CASES=<n>: a longer one-off sweep, e.g. together with GM_NORMALS_ROWS=2|4 to drive the fine-row kernel or
-#  GM_FUZZ_FLAGS=64 to replay every frame from a captured graph)
+# (GM_FUZZ_CASES=<n>: a longer one-off sweep)
 CASES = list(range(int(os.environ.get("GM_FUZZ_CASES", "28"))))
+# Every case runs on the default path; six of them again on the fine-row instantiation of the neighbourhood kernel (y/z
+# rows r/2 and r/4 wide: GM_NORMALS_ROWS, read per context) and two replayed from a captured graph (GM_CFG_GRAPH): the
+# same oracle, the same tolerances.
+VARIANTS = [(c, "default") for c in CASES] + [(0, "rows2"), (5, "rows4"), (7, "rows2"), (10, "rows4"), (15, "rows2"), (21, "rows4"),
+                                              (3, "graph"), (16, "graph")]
+OBSERVED = {}
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_random_frame_matches_oracle(gm, oc, case):
+@pytest.mark.parametrize("case,variant", VARIANTS)
+def test_random_frame_matches_oracle(gm, oc, case, variant, monkeypatch):
     from geometric_mapping_amd import _lib
+    if variant.startswith("rows"):
+        monkeypatch.setenv("GM_NORMALS_ROWS", variant[4:])
+    else:
+        monkeypatch.delenv("GM_NORMALS_ROWS", raising=False)
+    extra_flags = _lib.GM_CFG_GRAPH if variant == "graph" else int(os.environ.get("GM_FUZZ_FLAGS", "0"))
     rng = np.random.default_rng(1000 + case)
     kind = ["tunnel", "blob", "uniform", "plane", "dupes"][case % 5]
     n = int(rng.choice([1, 2, 3, 7, 64, 65, 1000, 2047, 2048, 2049, 5000, 20000]))
@@ -68,8 +78,10 @@ def test_random_frame_matches_oracle(gm, oc, case):
     step, offs = [(12, (0, 4, 8)), (16, (0, 4, 8)), (32, (8, 12, 16)), (22, (2, 6, 10))][case % 4]
     rows = synth.to_pointcloud2(xyz, point_step=step, offsets=offs, fill=0x5A)
     with gm.GeometricMapping(boxFilterBound=bound, voxelGridLeafSize=leaf, neighborRadius=radius, weightingFactor=wf,
-                             flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_KEEP_COUNTS | int(os.environ.get("GM_FUZZ_FLAGS", "0"))) as c:
+                             flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_KEEP_COUNTS | extra_flags) as c:
         res = c.process_frame(c.cloud_from_rows(rows, len(xyz), step, offs))
+        if variant == "graph":      # the second frame of a context is the replayed one
+            res = c.process_frame(c.cloud_from_rows(rows, len(xyz), step, offs))
         cloud, crows = c.cropped_cloud()
         nrm = c.normals()
         cnt = c.neighbor_counts()
@@ -92,17 +104,73 @@ def test_random_frame_matches_oracle(gm, oc, case):
             a = ang(nrm[:, :3], o["normals"][:, :3])
             well = o_cnt[valid] >= 8
             if well.any():
-                # 2e-5 rad, or -- where the neighbourhoods are ill-conditioned (near-isotropic covariance: a uniform
-                # cloud seen through a radius larger than the box) -- half of what the reference's own fp32 arithmetic
-                # (the oracle's f32_faithful mode) is away from the f64 value
+                # (ill-conditioned = near-isotropic covariance: a uniform cloud seen through a radius larger than the box;
+                # the reference's own fp32 arithmetic = the oracle's f32_faithful mode)
                 o32 = oc.normals(xyz[keep], radius, oc.F32_FAITHFUL)[0][valid]
                 fin = well & np.isfinite(o32[:, 0])
                 ref_dev = np.quantile(ang(o32[fin, :3], o["normals"][fin, :3]), 0.98) if fin.any() else 0.0
-                assert np.quantile(a[well], 0.98) < max(2e-5, 0.5 * ref_dev), (kind, n, radius, ref_dev)
+                q98 = float(np.quantile(a[well], 0.98))
+                OBSERVED[f"{case}/{variant}"] = {"kind": kind, "n": int(len(xyz)), "radius": radius, "angle_q98": q98, "ref_dev_q98": float(ref_dev)}
+                # north_star's 1e-5 (observed over the 28 cases: <= 3e-6 on well-conditioned neighbourhoods), or -- where
+                # the neighbourhoods are ill-conditioned -- half of the reference's own fp32 deviation from the f64 value
+                assert q98 < max(1e-5, 0.5 * ref_dev), (kind, n, radius, ref_dev)
         M = o["M"]
         if np.abs(M).max() > 0:
-            assert np.abs(res["scatter"] - M).max() / np.abs(M).max() < 2e-4
+            rel = float(np.abs(res["scatter"] - M).max() / np.abs(M).max())
+            OBSERVED.setdefault(f"{case}/{variant}", {})["scatter_rel"] = rel
+            assert rel < 1e-5     # (observed: <= 1.4e-6)
     else:
         assert set(crows.tolist()) <= set(keep.tolist()) and np.all(np.diff(crows) > 0)
     assert np.isfinite(res["eigenvalues"]).all() and np.isfinite(res["eigenvectors"]).all()
     assert np.all(np.diff(res["eigenvalues"]) >= -1e-3 * max(1.0, abs(res["eigenvalues"][2])))
+
+
+def test_fuzz_observations_are_written(gm):
+    """(runs last in this file) what the cases above observed, for tightening the bounds: gpurun_out/fuzz_observed.json"""
+    import json
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "fuzz_observed.json"), "w") as f:
+        json.dump(OBSERVED, f, indent=1, sort_keys=True)
+    assert len(OBSERVED) > 0
+
+
+def test_validity_on_duplicate_heavy_clouds_is_pinned_where_it_is_defined(gm, oc):
+    """Which points lose their normal (removeNaNNormalsFromPointCloud, src/tunnel_processing.cpp:74-85) on a cloud of
+    duplicated sites?  A neighbourhood whose covariance is exactly singular has no smallest eigenvector: PCL divides a
+    rounding-noise cross product there, and the restatements disagree among themselves (4 000 points on 400 sites:
+    every point kept by PCL <= 1.9's float sums, 3 620 by an exact evaluation).  The product's contract:
+      * fewer than 3 neighbours (the point included): removed -- exact, every implementation agrees;
+      * a neighbourhood on which BOTH the f64 evaluation and the f32-faithful restatement yield a finite normal (a
+        well-posed plane fit): kept, and the normal is the oracle's;
+      * anything else (all neighbours coincident or collinear up to rounding): unspecified -- kept or removed."""
+    from geometric_mapping_amd import _lib
+    rng = np.random.default_rng(77)
+    base = rng.uniform(-2, 2, (400, 3)).astype(np.float32)
+    xyz = base[rng.integers(len(base), size=4000)]
+    xyz = np.vstack([xyz, rng.uniform(-2, 2, (300, 3)).astype(np.float32)])      # some ordinary points among them
+    radius = 0.3
+    with gm.GeometricMapping(boxFilterBound=5.0, neighborRadius=radius, flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_KEEP_COUNTS) as c:
+        res = c.process_frame(xyz)
+        cloud, crows = c.cropped_cloud()
+        nrm = c.normals()
+        cnt = c.neighbor_counts()
+    keep = oc.crop_box(xyz, 5.0)
+    n64, c64 = oc.normals(xyz[keep], radius, oc.F64)
+    n32, _ = oc.normals(xyz[keep], radius, oc.F32_FAITHFUL)
+    assert np.array_equal(cnt, c64)
+    kept = np.zeros(len(keep), bool)
+    kept[np.searchsorted(keep, crows)] = True
+    must_drop = c64 < 3
+    fin64 = np.zeros(len(keep), bool); fin64[oc.finite_normals(n64)] = True      # (finite_normals returns the kept indices)
+    fin32 = np.zeros(len(keep), bool); fin32[oc.finite_normals(n32)] = True
+    must_keep = fin64 & fin32
+    assert not kept[must_drop].any()
+    assert kept[must_keep].all()
+    assert res["n_valid"] == int(kept.sum()) and must_keep.sum() > 300
+    # where the two restatements agree on the direction (a well-conditioned fit, not rounding noise that happens to be
+    # finite in both), the product's normal is theirs
+    agree = must_keep.copy()
+    agree[must_keep] = ang(n64[must_keep, :3], n32[must_keep, :3]) < 1e-3
+    if agree.any():
+        pos = np.searchsorted(keep[kept], keep[agree])
+        assert np.quantile(ang(nrm[pos, :3], n64[agree, :3]), 0.98) < 1e-3
