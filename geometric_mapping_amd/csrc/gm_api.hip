@@ -217,7 +217,7 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
     sl.tiles_cap = cap + 2u;  // every tile holds >= 1 point
     GM_HIP(ctx, dmalloc(sl.tiles, sl.tiles_cap));
     GM_HIP(ctx, dmalloc(sl.row_bounds, (size_t)1024 * 1024));  // make_grid caps every axis at 1024 cells
-    sl.blk_cap = compact_blocks(cap > kVoxDenseMaxCells ? cap : kVoxDenseMaxCells) + 1;
+    sl.blk_cap = compact_records(cap > kVoxDenseMaxCells ? cap : kVoxDenseMaxCells) + 1;
     GM_HIP(ctx, dmalloc(sl.tile_partials, (size_t)compact_blocks(cap) * 6));
     GM_HIP(ctx, dmalloc(sl.blk, (size_t)sl.blk_cap + 1));  // + the ticket word
     GM_HIP(ctx, hipMemsetAsync(sl.blk, 0, sizeof(unsigned long long) * ((size_t)sl.blk_cap + 1), sl.stream));
@@ -334,7 +334,8 @@ static gm_status enqueue_launches(gm_ctx *ctx, Slot &sl, const RowLayout &rows, 
     launch_grid_and_normals(g, vd, sl, ns, (cf.flags & GM_CFG_KEEP_COUNTS) != 0, true, s);
     record(ctx, sl, 3);  // end of grid+normals; the kernel alone is bracketed by ev_k0/ev_k1
     // (getLocalFrame's scatter terms are summed by the compaction: one partial row per kCpTile cropped points)
-    const uint32_t nparts = launch_compact_valid(sl, ns, cf.weightingFactor, s);
+    uint32_t row_tile = kCpTile;
+    const uint32_t nparts = launch_compact_valid(sl, ns, cf.weightingFactor, s, &row_tile);
     record(ctx, sl, 4);
     record(ctx, sl, 5);
     sl.vox_sort_path = (cf.flags & GM_CFG_VOXEL_GRID) && !vd.enabled;
@@ -348,7 +349,7 @@ static gm_status enqueue_launches(gm_ctx *ctx, Slot &sl, const RowLayout &rows, 
     }
     record(ctx, sl, 6);
     if (cf.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)) {
-        const gm_status st = gm_enqueue_ransac(ctx, sl, ns, nparts, kCpTile);   // its closing launch also finalizes the frame
+        const gm_status st = gm_enqueue_ransac(ctx, sl, ns, nparts, row_tile);   // its closing launch also finalizes the frame
         if (st != GM_OK) return st;
     }
     if ((cf.flags & GM_CFG_NEAREST) && (cf.flags & GM_CFG_VOXEL_GRID)) {
@@ -358,7 +359,7 @@ static gm_status enqueue_launches(gm_ctx *ctx, Slot &sl, const RowLayout &rows, 
     }
     record(ctx, sl, 7);
     if (!(cf.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)))
-        launch_frame_finalize(sl.tile_partials, nparts, kCpTile, sl, s);
+        launch_frame_finalize(sl.tile_partials, nparts, row_tile, sl, s);
     GM_HIP(ctx, hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(FrameOut), hipMemcpyDeviceToHost, s));
     return GM_OK;
 }

@@ -34,11 +34,16 @@ struct NoPayload {};   // predicates that load nothing worth keeping
 #define GM_CPTHREADS 512
 #endif
 constexpr int kCpThreads = GM_CPTHREADS;
-constexpr int kCpItems = 8;
+#ifndef GM_CPITEMS
+#define GM_CPITEMS 8
+#endif
+constexpr int kCpItems = GM_CPITEMS;
 constexpr int kCpTile = kCpThreads * kCpItems;  // points per tile
 constexpr int kCpWaves = kCpThreads / kWave;
 
 inline uint32_t compact_blocks(uint32_t n) { return (n + kCpTile - 1) / kCpTile; }  // tiles of n points
+constexpr int kCpMinTile = 2048;   // no instantiation cuts finer: the records of a slot are sized by it
+inline uint32_t compact_records(uint32_t n) { return (n + kCpMinTile - 1) / kCpMinTile; }
 inline uint32_t compact_grid(uint32_t n) { return compact_blocks(n); }               // one block per tile
 
 // Pred: typedef ... Payload (what the predicate has loaded and the emit step needs again: kept in registers, not re-read);
@@ -48,17 +53,18 @@ inline uint32_t compact_grid(uint32_t n) { return compact_blocks(n); }          
 //       after the tile's last emit (per-tile state lives in the functor; finish() resets it)
 // The element count is *n_ptr (device-resident) or n_host; the grid is compact_grid(capacity): a block per tile.  The number of survivors
 // goes to total_out / total_out2 (either may be null) -- also when it is 0.
-template <class Pred, class Emit>
-__global__ __launch_bounds__(kCpThreads) void k_compact(Pred pred, Emit emit, const uint32_t *__restrict__ n_ptr,
+template <class Pred, class Emit, int THREADS = kCpThreads, int ITEMS = kCpItems>
+__global__ __launch_bounds__(THREADS) void k_compact(Pred pred, Emit emit, const uint32_t *__restrict__ n_ptr,
                                                             uint32_t n_host, ScanState st,
                                                             uint32_t *__restrict__ total_out,
                                                             uint32_t *__restrict__ total_out2)
 {
+    static_assert(THREADS * ITEMS >= kCpMinTile, "tile below the size the record arrays are laid out for");
     constexpr uint64_t kAggregate = 1ull << 32, kInclusive = 2ull << 32;
-    __shared__ uint32_t lb_sum[kCpWaves], lb_state[kCpWaves];
-    __shared__ uint32_t wcnt[2][kCpItems][kCpWaves];
+    __shared__ uint32_t lb_sum[(THREADS / kWave)], lb_state[(THREADS / kWave)];
+    __shared__ uint32_t wcnt[(THREADS / kWave)];
     const uint32_t n = n_ptr ? *n_ptr : n_host;
-    const uint32_t ntiles = (n + (uint32_t)kCpTile - 1u) / (uint32_t)kCpTile;
+    const uint32_t ntiles = (n + (uint32_t)(THREADS * ITEMS) - 1u) / (uint32_t)(THREADS * ITEMS);
     const int w = threadIdx.x / kWave, lane = lane_id();
     const uint32_t epoch = scan_epoch(st);
     const uint64_t tag = (uint64_t)epoch << 34;
@@ -70,31 +76,45 @@ __global__ __launch_bounds__(kCpThreads) void k_compact(Pred pred, Emit emit, co
         return;
     }
     __shared__ uint32_t s_tile;
+#ifdef GM_CP_DIAG_NOTICKET   // timing diagnostic only (tools/build_variants.sh): what the ticket costs
+    if (threadIdx.x == 0) s_tile = blockIdx.x;
+#else
     if (threadIdx.x == 0) {
         const uint32_t t = atomicAdd(st.ticket, 1u);
         if (t == gridDim.x - 1) atomicExch(st.ticket, 0u);  // every ticket of this launch has been taken
         s_tile = t;
     }
+#endif
     __syncthreads();
-    const int buf = 0;
     const uint32_t tile = s_tile;
     if (tile < ntiles) {   // uniform per block; nothing after the end is ever looked at
-        const uint32_t base = tile * (uint32_t)kCpTile;
-        uint64_t mask[kCpItems];  // wave-uniform
-        typename Pred::Payload pay[kCpItems];
+        const uint32_t base = tile * (uint32_t)(THREADS * ITEMS);
+        // A wave owns ITEMS * 64 CONSECUTIVE positions of the tile (item j of wave w: base + w * 64 ITEMS + 64 j + lane), so the
+        // survivors of everything before item (w, j) are those of the waves before w -- one LDS word per wave -- plus those
+        // of the wave's own earlier items, which it holds in scalar registers: the ranks need one barrier and (waves) LDS
+        // reads per thread.  (Items striding the whole block, position = base + 512 j + thread, needed an
+        // [items][waves] table and 2 x items x waves LDS reads per thread: 1 M-point crop 17.5 -> 15.9 us, 10 M-point
+        // crop with 1024 x 8 tiles 88 -> 80 us.)
+        uint64_t mask[ITEMS];  // wave-uniform
+        typename Pred::Payload pay[ITEMS];
+        const uint32_t wbase = base + (uint32_t)w * (uint32_t)(kWave * ITEMS);
+        uint32_t wtotal = 0;
 #pragma unroll
-        for (int j = 0; j < kCpItems; ++j) {
-            const uint32_t i = base + j * kCpThreads + threadIdx.x;
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint32_t i = wbase + j * kWave + lane;
             const bool v = (i < n) && pred(i, pay[j]);
             mask[j] = __ballot(v);
-            if (lane == 0) wcnt[buf][j][w] = (uint32_t)__popcll(mask[j]);
+            wtotal += (uint32_t)__popcll(mask[j]);
         }
+        if (lane == 0) wcnt[w] = wtotal;
         __syncthreads();
-        uint32_t total = 0;
+        uint32_t total = 0, woff = 0;
 #pragma unroll
-        for (int j = 0; j < kCpItems; ++j)
-#pragma unroll
-            for (int k = 0; k < kCpWaves; ++k) total += wcnt[buf][j][k];
+        for (int k = 0; k < (THREADS / kWave); ++k) {
+            const uint32_t c = wcnt[k];
+            if (k < w) woff += c;
+            total += c;
+        }
         if (threadIdx.x == 0)
             __hip_atomic_store(&st.status[tile], tag | (tile == 0 ? kInclusive : kAggregate) | total, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -102,7 +122,12 @@ __global__ __launch_bounds__(kCpThreads) void k_compact(Pred pred, Emit emit, co
         // run at once, so inclusive prefixes are rare when the walk starts and a 64-wide window would need several
         // dependent round trips through the fabric; 512 records per trip cover a 2 M-point span.
         uint32_t before = 0;
+#ifdef GM_CP_DIAG_NOLOOKBACK   // timing diagnostic only, WRONG output (survivors of a tile written at the tile's own base): what the chain costs
+        before = base;
+        if (false) {
+#else
         if (tile > 0) {
+#endif
             int32_t top = (int32_t)tile - 1;
             for (;;) {
                 const int32_t idx = top - (int32_t)threadIdx.x;
@@ -124,7 +149,7 @@ __global__ __launch_bounds__(kCpThreads) void k_compact(Pred pred, Emit emit, co
                 uint32_t acc = 0;
                 bool retry = false, done = false;
 #pragma unroll
-                for (int k = 0; k < kCpWaves; ++k) {
+                for (int k = 0; k < (THREADS / kWave); ++k) {
                     if (!done && !retry) {
                         if (lb_state[k] == 2u) retry = true;
                         else { acc += lb_sum[k]; done = lb_state[k] == 1u; }
@@ -133,29 +158,27 @@ __global__ __launch_bounds__(kCpThreads) void k_compact(Pred pred, Emit emit, co
                 if (retry) { __builtin_amdgcn_s_sleep(2); continue; }
                 before += acc;
                 if (done) break;
-                top -= kCpThreads;
+                top -= THREADS;
             }
             if (threadIdx.x == 0)
                 __hip_atomic_store(&st.status[tile], tag | kInclusive | (uint64_t)(before + total), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
         if (threadIdx.x == 0 && tile == ntiles - 1) {  // the last tile knows the number of survivors
+#ifdef GM_CP_DIAG_NOLOOKBACK
+            if (total_out) *total_out = 0;    // (nothing downstream may look at the holes)
+            if (total_out2) *total_out2 = 0;
+#else
             if (total_out) *total_out = before + total;
             if (total_out2) *total_out2 = before + total;
+#endif
         }
-        uint32_t running = before;
+        uint32_t running = before + woff;
 #pragma unroll
-        for (int j = 0; j < kCpItems; ++j) {
-            const uint32_t i = base + j * kCpThreads + threadIdx.x;
-            uint32_t woff = 0, tot = 0;
-#pragma unroll
-            for (int k = 0; k < kCpWaves; ++k) {
-                const uint32_t c = wcnt[buf][j][k];
-                if (k < w) woff += c;
-                tot += c;
-            }
-            if ((mask[j] >> lane) & 1ull) emit(i, running + woff + (uint32_t)__popcll(mask[j] & lanemask_lt()), pay[j]);
-            running += tot;
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint32_t i = wbase + j * kWave + lane;
+            if ((mask[j] >> lane) & 1ull) emit(i, running + (uint32_t)__popcll(mask[j] & lanemask_lt()), pay[j]);
+            running += (uint32_t)__popcll(mask[j]);
         }
         if constexpr (Emit::kHasFinish) emit.finish(tile);
     }

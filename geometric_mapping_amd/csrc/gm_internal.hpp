@@ -156,7 +156,7 @@ uint32_t max_tiles(uint32_t n_cap, const GridParams &g);
 // k_frame.hip
 // NaN-normal compaction; also leaves the scatter-matrix partial rows of the survivors in sl.tile_partials (one per
 // kCpTile cropped points); returns the number of rows launched
-uint32_t launch_compact_valid(Slot &sl, uint32_t n_cap, double weightingFactor, hipStream_t s);
+uint32_t launch_compact_valid(Slot &sl, uint32_t n_cap, double weightingFactor, hipStream_t s, uint32_t *row_tile = nullptr);
 // scatter partials over vnorm4[0..n); returns the number of partial rows written
 uint32_t launch_scatter_partials(const float4 *vnorm4, const uint32_t *n_ptr, uint32_t n_cap, double wf, Slot &sl,
                                  hipStream_t s);

@@ -24,7 +24,7 @@ struct RowReader {
     {
         const uint8_t *row = L.data + (size_t)i * L.step;
         if (L.mode == 0) {
-            float4 v = *reinterpret_cast<const float4 *>(row);
+            const float4 v = *reinterpret_cast<const float4 *>(row);   // (a non-temporal load here: no change, 91.2 vs 90.7 us at 10 M points)
             x = v.x; y = v.y; z = v.z;
         } else if (L.mode == 1) {
             x = *reinterpret_cast<const float *>(row + L.ox);
@@ -63,6 +63,10 @@ struct CropEmit {
     GridParams g;
     float4 *__restrict__ crop4;
     uint32_t *__restrict__ keys;
+    // (The keys leave as one dword per lane, 256 bytes per store instruction; tools/microbench_stream.hip prices those 33 MB
+    // of the 10 M-point frame at 14 us, as much as 80 MB of 16-byte-per-lane stores.  Collecting a wave's keys in LDS --
+    // its survivors are consecutive in the output -- and writing them 16 bytes per lane was measured: 80 -> 86 us, the
+    // stores then wait for the wave's last item.)
     __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst, const CropPred::Payload &p) const
     {
         crop4[dst] = make_float4(p.x, p.y, p.z, __uint_as_float(src));
@@ -98,13 +102,30 @@ void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const Gr
                  uint32_t n_size, const uint32_t *n_dev)
 {
     if (n_size < n) n_size = n;
-    const uint32_t nb = compact_blocks(n_size);
-    if (nb == 0) return;  // counters were zeroed: n_cropped stays 0
+    if (n_size == 0) return;  // counters were zeroed: n_cropped stays 0
     RowReader rd{rows};
     CropPred pred{rd, lo, hi};
     CropEmit emit{rd, g, sl.crop4, sl.keys_a};
-    hipLaunchKernelGGL((k_compact<CropPred, CropEmit>), dim3(compact_grid(n_size)), dim3(kCpThreads), 0, s, pred, emit,
-                       n_dev, n, next_scan(sl), &sl.ctr->n_cropped, (uint32_t *)nullptr);
+    // Tile shape: 512 threads x 8 rows, and 1024 x 8 for frames beyond 2 M points.  Every tile costs a ticket and a
+    // look-back; with every block slot of the chip taken (2.4 rounds of 4096-point tiles at 10 M points) twice the tile
+    // is 107 -> 80 us on the 10 M-point frame and 34.5 -> 31 us at 3 M, while the 1 M-point frame (204 tiles for 256 CUs)
+    // wants the small one (17.5 against 21 us for 512 x 16).  Measured around it at 10 M points: 512x16 89 us, 512x24
+    // 86, 512x32 116, 1024x12 85, 1024x16 91, 256x32 100, 512x4 and 256x8 143; MORE resident blocks per CU are slower
+    // (1024x8 held to 64 registers, two blocks per CU: 103 us; 512x16 at three per CU: 91), fewer too (512x8, one per
+    // CU: 131).  What the pattern allows without any scan: tools/microbench_stream.hip, 66-74 us.
+    // GM_CROP_TILE=<threads>x<items>: experiments.
+    static const char *e = getenv("GM_CROP_TILE");
+    int th = 512, it = 8;
+    if (e) sscanf(e, "%dx%d", &th, &it);
+    else if (n_size > 2000000u) th = 1024;
+    const ScanState st = next_scan(sl);
+#define GM_CROP_LAUNCH(T, I)                                                                                              \
+    hipLaunchKernelGGL((k_compact<CropPred, CropEmit, T, I>), dim3((n_size + (T) * (I) - 1u) / ((T) * (I))), dim3(T), 0, s, pred, \
+                       emit, n_dev, n, st, &sl.ctr->n_cropped, (uint32_t *)nullptr)
+    if (th == 1024 && it == 8) GM_CROP_LAUNCH(1024, 8);
+    else if (th == 512 && it == 16) GM_CROP_LAUNCH(512, 16);
+    else GM_CROP_LAUNCH(512, 8);
+#undef GM_CROP_LAUNCH
 }
 
 }  // namespace gm

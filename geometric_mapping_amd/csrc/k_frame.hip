@@ -131,14 +131,27 @@ void launch_minmax(const float4 *pts, const uint32_t *n_ptr, uint32_t n_cap, Dev
     hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(256), 0, s, pts, n_ptr, n_cap, ctr);
 }
 
-uint32_t launch_compact_valid(Slot &sl, uint32_t n_cap, double wf, hipStream_t s)
+uint32_t launch_compact_valid(Slot &sl, uint32_t n_cap, double wf, hipStream_t s, uint32_t *row_tile)
 {
-    const uint32_t nb = compact_blocks(n_cap);
+    // Tile: 4096 points (512 threads x 8); 8192 (1024 x 8) for frames of several million points, as for the crop
+    // (k_crop.hip: fewer tickets and look-backs per byte).  GM_VALID_TILE=<threads>x<items>: experiments.
+    static const char *e = getenv("GM_VALID_TILE");
+    int th = 512, it = 8;
+    if (e) sscanf(e, "%dx%d", &th, &it);
+    else if (n_cap > 2000000u) { th = 1024; it = 8; }   // (10 M points: 122 -> 109 us; 3 M: 44 -> 38)
+    const bool big = th == 1024 && it == 8;
+    const uint32_t tile = big ? 8192u : (uint32_t)kCpTile;
+    if (row_tile) *row_tile = tile;
+    const uint32_t nb = (n_cap + tile - 1) / tile;
     if (nb == 0) return 0;
     ValidPred pred{sl.normals4};
     ValidEmit emit{sl.crop4, sl.valid4, sl.vnorm4, .001 / wf, sl.tile_partials, {0, 0, 0, 0, 0, 0}};
-    hipLaunchKernelGGL((k_compact<ValidPred, ValidEmit>), dim3(compact_grid(n_cap)), dim3(kCpThreads), 0, s, pred, emit,
-                       (const uint32_t *)&sl.ctr->n_cropped, 0u, next_scan(sl), &sl.ctr->n_valid, &sl.ctr->vox_n);
+    if (big)
+        hipLaunchKernelGGL((k_compact<ValidPred, ValidEmit, 1024, 8>), dim3(nb), dim3(1024), 0, s, pred, emit,
+                           (const uint32_t *)&sl.ctr->n_cropped, 0u, next_scan(sl), &sl.ctr->n_valid, &sl.ctr->vox_n);
+    else
+        hipLaunchKernelGGL((k_compact<ValidPred, ValidEmit>), dim3(nb), dim3(kCpThreads), 0, s, pred, emit,
+                           (const uint32_t *)&sl.ctr->n_cropped, 0u, next_scan(sl), &sl.ctr->n_valid, &sl.ctr->vox_n);
     return nb;  // partial rows: one per tile that held input (the finalizer derives how many from n_cropped)
 }
 

@@ -18,5 +18,13 @@ python3 tools/summarize_profiles.py $OUT $TAG
 # 10 M-point frame (BASELINE configs[2]: plane + cylinder RANSAC): per-kernel durations for the streaming-kernel roofline rows
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace10m -- python3 $ROOT/tools/stage_times.py --points 10000000 --flags 12 --reps 5 > $OUT/stage10m.log 2>&1 || exit 4
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc10m_fetch -- python3 $ROOT/tools/stage_times.py --points 10000000 --flags 12 --reps 3 > $OUT/stage10m_fetch.log 2>&1 || echo "10 M FETCH_SIZE pass failed"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc10m_write -- python3 $ROOT/tools/stage_times.py --points 10000000 --flags 12 --reps 3 > $OUT/stage10m_write.log 2>&1 || echo "10 M WRITE_SIZE pass failed"
 cd $ROOT
-python3 tools/streaming_roofline.py "$(ls $OUT/trace10m/*/*kernel_stats.csv | tail -1)" $OUT/stage10m.log $OUT/summary/${TAG}_streaming_kernels_10M.json
+cp "$(ls $OUT/trace10m/*/*kernel_stats.csv | tail -1)" $OUT/summary/${TAG}_kernel_stats_10M.csv
+python3 tools/streaming_roofline.py "$(ls $OUT/trace10m/*/*kernel_stats.csv | tail -1)" $OUT/stage10m.log $OUT/summary/${TAG}_streaming_kernels_10M.json $OUT/pmc10m_fetch $OUT/pmc10m_write
+# one frame at a time (no other frame's kernels beside it): the exclusive per-kernel durations
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_one -- python3 $ROOT/tools/stage_times.py --flags 8 --reps 40 > $OUT/stage_one.log 2>&1 || exit 5
+cd $ROOT
+cp "$(ls $OUT/trace_one/*/*kernel_stats.csv | tail -1)" $OUT/summary/${TAG}_kernel_stats_one_frame.csv

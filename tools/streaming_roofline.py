@@ -2,14 +2,30 @@
 """Per-kernel HBM roofline rows of the STREAMING kernels from a rocprofv3 kernel-stats CSV of one
 frame size (tools/stage_times.py under rocprofv3 --kernel-trace --stats).
 
-usage: streaming_roofline.py <kernel_stats.csv> <stage_times.log> <out.json>
+usage: streaming_roofline.py <kernel_stats.csv> <stage_times.log> <out.json> [<pmc_fetch_dir> <pmc_write_dir>]
+
+With the two rocprofv3 --pmc output directories (FETCH_SIZE and WRITE_SIZE passes of the same command) every row also
+carries the bytes the counters saw: hbm_bytes_pmc = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950 counts a
+wide coalesced read at half its bytes, MI355X_MICROARCH.md par. HBM).
 
 Algorithmic bytes follow SURVEY.md par. 8(d) (each array touched once; float4 rows counted at the
 12 B of x,y,z they carry, normals at 16 B); `bytes_moved` is what the kernel really loads/stores
 (16-byte rows).  Peak: 8.0 TB/s spec, 6.29 TB/s measured copy peak (MI355X_MICROARCH.md)."""
 import csv, json, sys
 
+import collections, glob, os
 stats, log, out = sys.argv[1:4]
+pmc = {}
+if len(sys.argv) >= 6:
+    for d, name in ((sys.argv[4], "FETCH_SIZE"), (sys.argv[5], "WRITE_SIZE")):
+        acc = collections.defaultdict(list)
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == name:
+                    acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            v = v[len(v) // 3:]   # (drop the warm-up launches: smaller buffers are not touched yet)
+            pmc.setdefault(k, {})[name] = sum(v) / len(v)
 meta = {}
 for line in open(log):
     if line.startswith("{"):
@@ -45,14 +61,29 @@ rows = {
 }
 res = {"points": n_in, "n_cropped": n_c, "n_valid": n_v, "radius": meta.get("radius"),
        "peak_spec_GBs": 8000.0, "peak_measured_copy_GBs": 6290.0, "kernels": {}}
+def find(table, key):
+    """exact name, or the instantiation of it that carries further template arguments (the compactions' tile shape)"""
+    if key in table:
+        return table[key]
+    if key.endswith(">") and "k_compact" in key:
+        hits = [k for k in table if k.startswith(key[:-1] + ",")]
+        if hits:
+            return table[max(hits, key=lambda k: table[k][1] if isinstance(table[k], tuple) else 0)]
+    return None
 for k, (what, alg, moved) in rows.items():
-    if k not in dur:
+    if find(dur, k) is None:
         continue
-    t, calls = dur[k]
+    t, calls = find(dur, k)
     res["kernels"][k] = {"reference_step": what, "avg_us": round(t * 1e6, 2), "calls": calls,
                          "algorithmic_bytes": alg, "algorithmic_GBs": round(alg / t / 1e9, 1),
                          "frac_of_spec": round(alg / t / 8.0e12, 3), "frac_of_measured_peak": round(alg / t / 6.29e12, 3),
                          "bytes_moved": moved, "moved_GBs": round(moved / t / 1e9, 1)}
+    pk = find(pmc, k)
+    if pk and "FETCH_SIZE" in pk and "WRITE_SIZE" in pk:
+        pmc[k] = pk
+        b = (2.0 * pmc[k]["FETCH_SIZE"] + pmc[k]["WRITE_SIZE"]) * 1024.0
+        res["kernels"][k].update({"hbm_bytes_pmc": round(b), "pmc_GBs": round(b / t / 1e9, 1), "pmc_frac_of_spec": round(b / t / 8.0e12, 3),
+                                  "FETCH_SIZE_KiB": round(pmc[k]["FETCH_SIZE"], 1), "WRITE_SIZE_KiB": round(pmc[k]["WRITE_SIZE"], 1)})
 json.dump(res, open(out, "w"), indent=1)
 for k, v in res["kernels"].items():
     print(k[:52].ljust(52), "%8.1f us %8.1f GB/s alg (%.0f %% of spec)  %8.1f GB/s moved" %
