@@ -277,6 +277,22 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const float4 *__r
     }
 }
 
+// fp64 reciprocal / reciprocal square root from the hardware estimate (v_rcp_f64 / v_rsq_f64) and one Newton step:
+// ~2^-50 relative, 3-4 instructions where the IEEE division and sqrt sequences take ~30 each.  The epilogue below had five
+// divisions and three square roots per query; its results are rounded to float (normals, curvature) or feed a Newton
+// iteration, so correctly rounded quotients buy nothing.  x > 0 and normal everywhere they are used.
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double rsq_nr(double x)
+{
+    const double r = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x * r;
+    return fma(fma(-h, r, 0.5), r, r);
+}
+
 // ---- smallest eigenpair of a symmetric PSD 3x3, fp64 ----------------------------
 // c = {xx,xy,xz,yy,yz,zz}.  Root of the characteristic cubic: closed form with
 // fp32 trigonometry as the starting point, two Newton steps in fp64; eigenvector
@@ -293,10 +309,10 @@ __device__ __forceinline__ bool smallest_eigpair(const double c[6], double &lam,
     if (p > 0.0) {
         const double q = 0.5 * (k0 * (k3 * k5 - c[4] * c[4]) - c[1] * (c[1] * k5 - c[4] * c[2]) +
                                 c[2] * (c[1] * c[4] - k3 * c[2]));
-        const double sp = sqrt(p);
+        const double sp = p * rsq_nr(p);   // sqrt(p)
         double disc = p * p * p - q * q;
         if (disc < 0.0) disc = 0.0;
-        const float phi = atan2f((float)sqrt(disc), (float)q) * (1.0f / 3.0f);
+        const float phi = atan2f(disc > 0.0 ? (float)(disc * rsq_nr(disc)) : 0.0f, (float)q) * (1.0f / 3.0f);
         float sn, cs;
         __sincosf(phi, &sn, &cs);
         // smallest root of the three (phi in [0, pi/3])
@@ -308,7 +324,7 @@ __device__ __forceinline__ bool smallest_eigpair(const double c[6], double &lam,
             const double f = a * (b * d - c[4] * c[4]) - c[1] * (c[1] * d - c[4] * c[2]) + c[2] * (c[1] * c[4] - b * c[2]);
             const double fp = -(b * d + a * d + a * b - c[1] * c[1] - c[2] * c[2] - c[4] * c[4]);
             if (fabs(fp) > 1e-300) {
-                const double step = f / fp;
+                const double step = f * rcp_nr(fp);
                 // never step past the neighbouring root: |step| is bounded by the gap scale
                 if (fabs(step) < sp) l0 -= step;
             }
@@ -330,7 +346,7 @@ __device__ __forceinline__ bool smallest_eigpair(const double c[6], double &lam,
     else if (n2 >= n1 && n2 >= n3) { v[0] = v2[0]; v[1] = v2[1]; v[2] = v2[2]; nn = n2; }
     else { v[0] = v3[0]; v[1] = v3[1]; v[2] = v3[2]; nn = n3; }
     if (!(nn > 0.0)) return false;
-    const double inv = 1.0 / sqrt(nn);
+    const double inv = rsq_nr(nn);
     v[0] *= inv; v[1] *= inv; v[2] *= inv;
     return true;
 }
@@ -349,7 +365,7 @@ __device__ __forceinline__ bool emit_normal(bool active, const float4 q, const d
         const uint32_t dst = __float_as_uint(q.w);
         float4 out = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
         if (cnt >= 3) {
-            const double inv_n = 1.0 / (double)cnt;
+            const double inv_n = rcp_nr((double)cnt);
             const double mx = mom[1] * inv_n, my = mom[2] * inv_n, mz = mom[3] * inv_n;
             double c[6];
             c[0] = mom[4] * inv_n - mx * mx; c[1] = mom[5] * inv_n - mx * my; c[2] = mom[6] * inv_n - mx * mz;
@@ -357,7 +373,7 @@ __device__ __forceinline__ bool emit_normal(bool active, const float4 q, const d
             double lam, nv[3];
             if (smallest_eigpair(c, lam, nv)) {
                 const double trc = c[0] + c[3] + c[5];
-                const double curv = (trc != 0.0) ? fabs(lam / trc) : 0.0;
+                const double curv = (trc != 0.0) ? fabs(lam * rcp_nr(trc)) : 0.0;
                 const double ct = -((double)q.x * nv[0] + (double)q.y * nv[1] + (double)q.z * nv[2]);
                 const double sgn = (ct < 0.0) ? -1.0 : 1.0;
                 out = make_float4((float)(sgn * nv[0]), (float)(sgn * nv[1]), (float)(sgn * nv[2]), (float)curv);
