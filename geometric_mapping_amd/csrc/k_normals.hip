@@ -357,7 +357,7 @@ __device__ __forceinline__ bool smallest_eigpair(const double c[6], double &lam,
 // Returns whether the point enters the voxel grid (finite normal and owned by this rank's slab).
 __device__ __forceinline__ bool emit_normal(bool active, const float4 q, const double mom[10], const VoxDense &vd,
                                             float4 *__restrict__ normals4, int32_t *__restrict__ counts, uint32_t qn,
-                                            unsigned long long stat_t0)
+                                            unsigned long long stat_t0, unsigned long long stat_entry = 0ull)
 {
     bool vox_ok = false;
     const int cnt = (int)mom[0];
@@ -391,6 +391,8 @@ __device__ __forceinline__ bool emit_normal(bool active, const float4 q, const d
             const int lane = lane_id();
             if (counts && qn >= 2 && lane == 0) counts[dst] = -(int)((t1 & 0x1FFFFFFFull) | 0x20000000ull);  // end tick, bit 29 set
             if (counts && qn >= 2 && lane == 1) counts[dst] = -(int)((t1 - stat_t0) & 0xFFFFFull) - 1;        // duration < 2^20 ticks
+            // lane 2: ticks between the wave's first instruction and the start of its tile (bit 28 marks it)
+            if (counts && qn >= 3 && lane == 2 && stat_entry) counts[dst] = -(int)(((stat_t0 - stat_entry) & 0xFFFFFull) | 0x10000000ull);
         }
 #endif
     }
@@ -1052,7 +1054,8 @@ __device__ unsigned long long gm_phase_ticks[16];
 // FINE = false: the usual grid (cells one radius wide, 3 x 3 rows: everything about rows is a compile-time constant);
 // FINE = true: y/z rows finer than the radius (GridParams::D > 1), chosen for frames with very many neighbours per point.
 template <bool FINE>
-__device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned char *lds, const uint2 tile, uint32_t min_candidates)
+__device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned char *lds, const uint2 tile, uint32_t min_candidates,
+                                                 unsigned long long stat_entry = 0ull)
 {
     const float4 *__restrict__ spts4 = A.spts4;
     const uint32_t *__restrict__ skeys = A.skeys;
@@ -1524,7 +1527,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         uint32_t qidx_e = qs + (active ? (uint32_t)lane : qn - 1u);
         asm volatile("" : "+v"(qidx_e));
         const float4 qe = spts4[qidx_e];
-        const bool vox_ok = emit_normal(active, qe, mom, vd, normals4, counts, qn, stat_t0);
+        const bool vox_ok = emit_normal(active, qe, mom, vd, normals4, counts, qn, stat_t0, stat_entry);
         if (vd.enabled) voxel_sums(vox_ok, qe, vd, vox_table);
         GM_PH_STAMP(ph_t4);
         GM_PH_ADD(5, ph_t4 - ph_t3);   // moments -> normal, stores, voxel sums
@@ -1588,6 +1591,11 @@ template <bool FINE>
 __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs A, uint32_t mx_min_candidates)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][(kMdWaveLdsBytes + 15) / 16 * 16];
+#ifdef GM_NORMALS_TIMELINE
+    const unsigned long long stat_entry = wall_clock64();
+#else
+    const unsigned long long stat_entry = 0ull;
+#endif
     uint32_t ntiles = A.ctr->n_tiles;
     if (ntiles > A.tiles_cap) ntiles = A.tiles_cap;
     const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
@@ -1600,7 +1608,7 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs
         uint4 *z = reinterpret_cast<uint4 *>(lds[wv]);
         for (int i = lane_id(); i < kMdWaveLdsBytes / 16; i += kWave) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    normals_tile_mxd<FINE>(A, lds[wv], A.tiles[wave_id], mx_min_candidates);
+    normals_tile_mxd<FINE>(A, lds[wv], A.tiles[wave_id], mx_min_candidates, stat_entry);
     if (ntiles > n_waves && wave_id != 0xFFFFFFFFu)
         for (uint32_t t = wave_id + n_waves; t < ntiles; t += n_waves)
             normals_tile_mxd<FINE>(A, lds[wv], A.tiles[t], mx_min_candidates);
