@@ -1501,16 +1501,22 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         // query is query (lane & 31) of group (lane >> 5): it keeps its own half of that group's rows and swaps the
         // other group's registers with lane ^ 32 for the missing half.
         GM_PH_STAMP(ph_t3);
+        // (the lane id is taken afresh, behind an empty asm: carried across the candidate stream it was the one register the
+        // kernel spilled)
+        int lane_e = lane_id();
+        asm volatile("" : "+v"(lane_e));
+        const int half_e = lane_e >> 5;
+        const bool active_e = (uint32_t)lane_e < qn;
         float own[16], got[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            own[k] = half ? acc[1][k] : acc[0][k];
-            const float snd = half ? acc[0][k] : acc[1][k];
+            own[k] = half_e ? acc[1][k] : acc[0][k];
+            const float snd = half_e ? acc[0][k] : acc[1][k];
             got[k] = __shfl_xor(snd, 32, kWave);
         }
         auto frow = [&](int rr) -> double {  // feature row rr of the home query
             const int k = 4 * (rr >> 3) + (rr & 3), hh = (rr >> 2) & 1;
-            return (double)((hh == half) ? own[k] : got[k]);
+            return (double)((hh == half_e) ? own[k] : got[k]);
         };
         double mom[10];
         mom[0] = frow(0);
@@ -1524,10 +1530,10 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         // kernel sits at its 128-VGPR budget and everything live across the loop that the loop does not use was being
         // spilled once per tile -- 50 MB of scratch writes per launch.  (The index goes through an empty asm so that the
         // compiler cannot tell it is the load it already has.)
-        uint32_t qidx_e = qs + (active ? (uint32_t)lane : qn - 1u);
+        uint32_t qidx_e = qs + (active_e ? (uint32_t)lane_e : qn - 1u);
         asm volatile("" : "+v"(qidx_e));
         const float4 qe = spts4[qidx_e];
-        const bool vox_ok = emit_normal(active, qe, mom, vd, normals4, counts, qn, stat_t0, stat_entry);
+        const bool vox_ok = emit_normal(active_e, qe, mom, vd, normals4, counts, qn, stat_t0, stat_entry);
         if (vd.enabled) voxel_sums(vox_ok, qe, vd, vox_table);
         GM_PH_STAMP(ph_t4);
         GM_PH_ADD(5, ph_t4 - ph_t3);   // moments -> normal, stores, voxel sums
@@ -1609,9 +1615,11 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs
         for (int i = lane_id(); i < kMdWaveLdsBytes / 16; i += kWave) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     normals_tile_mxd<FINE>(A, lds[wv], A.tiles[wave_id], mx_min_candidates, stat_entry);
+#ifndef GM_NORMALS_NO_LOOP   // (experiment: the kernel without its looped copy -- frames with more tiles than waves unsupported)
     if (ntiles > n_waves && wave_id != 0xFFFFFFFFu)
         for (uint32_t t = wave_id + n_waves; t < ntiles; t += n_waves)
             normals_tile_mxd<FINE>(A, lds[wv], A.tiles[t], mx_min_candidates);
+#endif
 }
 
 // the all-VALU formulation of every tile (GM_NORMALS_IMPL=valu: A/B measurements and the cross-check in tests)

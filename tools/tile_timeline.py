@@ -36,6 +36,13 @@ hist, edges = np.histogram(-rel, bins=16)
 for h, e0, e1 in zip(hist, edges[:-1], edges[1:]):
     print("ends %6.1f - %6.1f us before the kernel ends: %6d tiles" % (e0, e1, h))
 
+# ---- how fast the chip fills: tiles started / in flight over the first microseconds
+_m = min(len(ends), len(durs))
+_e = (ends[:_m] - ends.min()) * us_per_tick
+_s = _e - durs[:_m]
+_t0 = _s.min()
+print(json.dumps({"ramp": {"%d us" % t: {"started": int((_s - _t0 <= t).sum()), "in_flight": int(((_s - _t0 <= t) & (_e - _t0 > t)).sum())} for t in (5, 10, 15, 20, 30, 40, 60, 80, 100, 120)}}))
+
 # ---- what would another dispatch order buy?  Greedy list scheduling of the measured durations on 4096 wave slots
 # (ignores that a tile runs faster on an emptier SIMD: an upper bound on the gain of reordering)
 import heapq
