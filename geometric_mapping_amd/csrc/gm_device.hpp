@@ -77,8 +77,9 @@ struct GridParams {
                         // inside the band and is re-evaluated exactly)
     float dband;        // band * dscale, in [1, 2)
     float band;         // half-width of the band around r2 inside which the distance MFMA's value does not decide a pair
-                        // (5e-5 * cell edge^2: >= 20x the error measured by tools/microbench/mfma_probe.hip for offsets
-                        // of the size a tile and its windows span)
+                        // (2e-5 * (1.001 r)^2, whatever D is: analytic worst case of the distance product 1.7e-5 of that
+                        // square, largest error measured by the diagnostic build over every tested pair of the 1 M-point frame
+                        // 4.2e-6 -- profiles/r02_distance_mfma_error.json, tools/microbench/mfma_probe.hip)
 };
 
 // Dense voxel table (fast path of the VoxelGrid stage): when the crop box bounds
