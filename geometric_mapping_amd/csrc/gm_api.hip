@@ -49,7 +49,7 @@ void free_slot_buffers(Slot &sl)
     sl.d_raw = nullptr; sl.h_raw = nullptr; sl.crop4 = nullptr; sl.keys_a = sl.keys_b = sl.vals_a = sl.vals_b = nullptr;
     sl.spts4 = sl.normals4 = sl.valid4 = sl.vnorm4 = sl.vox4 = nullptr; sl.counts = nullptr; sl.tiles = nullptr; sl.row_bounds = nullptr;
     sl.blk = nullptr; sl.tile_partials = nullptr; sl.sort.hist = nullptr; sl.seg_start = nullptr; sl.vox_nn = nullptr; sl.labels = nullptr;
-    sl.cap = 0; sl.raw_cap = 0; sl.tiles_cap = 0;
+    sl.cap = 0; sl.raw_cap = 0; sl.tiles_cap = 0; sl.tile_seg = 0;
 }
 
 // search grid over the crop box: cell edge >= 1.001 r in y and z (<= 1024 cells per axis), x binned
@@ -214,8 +214,11 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
     GM_HIP(ctx, dmalloc(sl.valid4, cap)); GM_HIP(ctx, dmalloc(sl.vnorm4, cap));
     GM_HIP(ctx, dmalloc(sl.seg_start, cap)); GM_HIP(ctx, dmalloc(sl.vox4, cap));
     GM_HIP(ctx, dmalloc(sl.vox_nn, cap)); GM_HIP(ctx, dmalloc(sl.labels, cap));
-    sl.tiles_cap = cap + 2u;  // every tile holds >= 1 point
-    GM_HIP(ctx, dmalloc(sl.tiles, sl.tiles_cap));
+    // tile list: kTileListClasses - 1 segments for the tiles with an x extent (>= 2 points each, a few per cent of cap in
+    // any real frame; a full one overflows into the last) + one that holds every tile a frame can have (>= 1 point each)
+    sl.tiles_cap = cap + 2u;
+    sl.tile_seg = cap / (uint32_t)kTileListClasses + 2u;
+    GM_HIP(ctx, dmalloc(sl.tiles, (size_t)(kTileListClasses - 1) * sl.tile_seg + sl.tiles_cap));
     GM_HIP(ctx, dmalloc(sl.row_bounds, (size_t)1024 * 1024));  // make_grid caps every axis at 1024 cells
     sl.blk_cap = compact_records(cap > kVoxDenseMaxCells ? cap : kVoxDenseMaxCells) + 1;
     GM_HIP(ctx, dmalloc(sl.tile_partials, (size_t)compact_blocks(cap) * 6));

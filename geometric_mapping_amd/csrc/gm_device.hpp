@@ -29,16 +29,25 @@ __device__ __forceinline__ uint32_t scan_epoch(const ScanState &st)
     return st.frame_ptr ? 0x20000000u + (((*st.frame_ptr) * 8u + st.epoch) & 0x1FFFFFFFu) : st.epoch;
 }
 
+#ifndef GM_TILE_CLASSES
+#define GM_TILE_CLASSES 8
+#endif
+constexpr int kTileListClasses = GM_TILE_CLASSES;   // cost classes of k_normals' tile list (k_normals.hip)
+
 struct DevCounters {
     uint32_t n_cropped;   // points surviving the crop box
     uint32_t n_valid;     // points with a finite normal (and owned, when sharded)
-    uint32_t n_tiles;     // query tiles built from the sorted cell keys
+    uint32_t n_tiles;     // (unused since the tile list has cost classes: n_tiles_c below)
     uint32_t reserved0;
     uint32_t n_voxels;    // occupied voxels
     uint32_t vox_n;       // points entering the voxel grid (= n_valid)
     uint32_t mm[6];       // ordered-uint encodings: min x,y,z then max x,y,z of the valid cloud
     uint32_t scratch_total;
     uint32_t pad[5];      // (diagnostic builds count candidate streams here)
+    // tiles per cost class (k_rows_and_tiles files a tile by its x extent; k_normals runs class 0 first), one counter per
+    // 128-byte line: every cutter block adds to every class, and returning atomics on one line are served one after the
+    // other (~88 per us) -- eight counters in one line cost the tile builder 4.5 us
+    uint32_t n_tiles_c[kTileListClasses][32];
 };
 static_assert(sizeof(DevCounters) % 8 == 0, "zero-filled in 8-byte words");
 

@@ -44,7 +44,8 @@ struct Slot {
     float4 *valid4 = nullptr;     // compacted cloud (finite normals)
     float4 *vnorm4 = nullptr;     // compacted normals
     uint2 *tiles = nullptr;
-    uint32_t tiles_cap = 0;
+    uint32_t tiles_cap = 0;   // entries of the tile list's last class (every tile of a frame fits)
+    uint32_t tile_seg = 0;    // entries of each of its other kTileListClasses - 1 classes
     uint2 *row_bounds = nullptr;  // [1024*1024] first / one-past-last sorted position per x-row of the search grid
     unsigned long long *blk = nullptr;  // tile records of the single-pass compactions 
     uint32_t blk_cap = 0;

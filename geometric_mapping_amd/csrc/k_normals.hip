@@ -82,6 +82,7 @@ __device__ __forceinline__ v2f pk_within(v2f d2, v2f neg_big, v2f r2_big)
 #endif
 constexpr int kNrThreads = GM_NRTHREADS;
 constexpr int kTileQ = kWave;             // queries per tile: one per lane
+constexpr int kTileClasses = kTileListClasses;   // cost classes of the tile list (gm_device.hpp)
 constexpr int kGroups = 4;                // lane groups with their own candidate window
 constexpr int kGroupLanes = kWave / kGroups;
 #ifndef GM_FOLD_TRIPS
@@ -121,10 +122,12 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const float4 *__r
                                                                DevCounters *__restrict__ ctr, uint32_t nx, uint32_t span,
                                                                float4 *__restrict__ spts4,
                                                                uint2 *__restrict__ row_bounds /* [ny*nz]: begin, end */,
-                                                               uint2 *__restrict__ tiles, uint32_t tiles_cap)
+                                                               uint2 *__restrict__ tiles, uint32_t tiles_cap, uint32_t tile_seg)
 {
-    __shared__ uint32_t wtot[kTbThreads / kWave], wstart[kTbThreads / kWave];
-    __shared__ uint32_t block_base, s_start0;
+    __shared__ uint32_t wstart[kTbThreads / kWave];
+    __shared__ uint32_t s_start0;
+    __shared__ uint32_t ccount[kTileClasses], cbase[kTileClasses];
+    if (threadIdx.x < kTileClasses) ccount[threadIdx.x] = 0u;   // (ordered before its use by the barriers below; the gather blocks return before them)
     const uint32_t n = ctr->n_cropped;
     const uint32_t base = (blockIdx.x >> 1) * (uint32_t)kTbSpan;
     if (base >= n) return;  // uniform per block
@@ -210,12 +213,12 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const float4 *__r
     uint32_t row_start = before ? before - 1u : s_start0;
     // a point starts a tile iff it starts a 64-chunk of its x-row, or its chunk is "sparse"
     // (spans more than `span` cell steps) and it is the first point of an aligned cell group
-    uint32_t cnt[kTbPer], tend[kTbPer], total_t = 0;
+    uint32_t cnt[kTbPer], tend[kTbPer], tcls[kTbPer];
     const uint32_t group = span + 1u;
 #pragma unroll
     for (int j = 0; j < kTbPer; ++j) {
         const uint32_t s = s0 + j;
-        cnt[j] = 0; tend[j] = 0;
+        cnt[j] = 0; tend[j] = 0; tcls[j] = 0;
         if (s < n) {
             if (starts[j]) row_start = s;
             const uint32_t r = row[j], kj = key[j + 1];
@@ -236,11 +239,13 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const float4 *__r
                     }
                     cend = lo;
                 }
-                const bool sparse = skeys[cend - 1] - skeys[cstart] > span;  // same row: key difference = cell steps
+                const uint32_t chunk_ext = skeys[cend - 1] - skeys[cstart];  // same row: key difference = cell steps
+                const bool sparse = chunk_ext > span;
                 if (at_cstart || sparse) {
                     cnt[j] = 1;
                     // the tile ends with its 64-chunk or, in a sparse chunk, where the next cell group begins
                     tend[j] = cend;
+                    uint32_t ext = chunk_ext;
                     if (sparse) {
                         uint32_t lo = s + 1, hi = cend;
                         while (lo < hi) {
@@ -248,31 +253,40 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const float4 *__r
                             if ((skeys[mid] - r * nx) / group == my_group) lo = mid + 1; else hi = mid;
                         }
                         tend[j] = lo;
+                        ext = skeys[lo - 1] - kj;
                     }
+                    // cost class: a tile's candidates are those of windows 2 r + its own x extent long in every row around
+                    // it -- their number follows the extent (correlation 0.99 on the 1 M-point frame), so the extent orders
+                    // the tiles by cost: class 0 = longest
+                    const uint32_t c8 = ext * (uint32_t)kTileClasses / group;
+                    tcls[j] = (uint32_t)(kTileClasses - 1) - (c8 < (uint32_t)kTileClasses - 1u ? c8 : (uint32_t)kTileClasses - 1u);
                 }
             }
         }
-        total_t += cnt[j];
     }
-    // block-wide exclusive prefix of the flags, ONE atomic per block for the base
-    const uint32_t inc = wave_inclusive_scan(total_t);
-    if (lane_id() == kWave - 1) wtot[w] = inc;
-    __syncthreads();
-    uint32_t woff = 0, total = 0;
+    // ---- the block files its tiles by class: rank inside the block from an LDS counter per class, ONE global atomic per
+    // block and class for the base.  (The order of the tiles inside a class is not fixed from run to run; nothing depends on
+    // it: a tile's results are its own.)  Classes 0 .. K-2 have tile_seg entries each; what does not fit goes to the last
+    // class, which can hold every tile of the frame.
+    uint32_t rank[kTbPer];
 #pragma unroll
-    for (int k = 0; k < kTbThreads / kWave; ++k) {
-        const uint32_t c = wtot[k];
-        if (k < w) woff += c;
-        total += c;
-    }
-    if (threadIdx.x == 0) block_base = total ? atomicAdd(&ctr->n_tiles, total) : 0u;
+    for (int j = 0; j < kTbPer; ++j) rank[j] = cnt[j] ? atomicAdd(&ccount[tcls[j]], 1u) : 0u;
     __syncthreads();
-    uint32_t t_out = block_base + woff + inc - total_t;
+    if (threadIdx.x < kTileClasses) {
+        const uint32_t c = ccount[threadIdx.x];
+        cbase[threadIdx.x] = c ? atomicAdd(&ctr->n_tiles_c[threadIdx.x][0], c) : 0u;
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < kTbPer; ++j) {
         if (cnt[j]) {
-            if (t_out < tiles_cap) tiles[t_out] = make_uint2(s0 + j, tend[j] - (s0 + j));  // first query, number of queries
-            ++t_out;
+            const uint2 t = make_uint2(s0 + j, tend[j] - (s0 + j));  // first query, number of queries
+            uint32_t c = tcls[j], idx = cbase[c] + rank[j];
+            if (c + 1u < (uint32_t)kTileClasses && idx >= tile_seg) {   // class segment full
+                c = (uint32_t)kTileClasses - 1u;
+                idx = atomicAdd(&ctr->n_tiles_c[c][0], 1u);
+            }
+            if (c + 1u < (uint32_t)kTileClasses || idx < tiles_cap) tiles[(size_t)c * tile_seg + idx] = t;
         }
     }
 }
@@ -443,7 +457,8 @@ struct NormalsArgs {
     const uint2 *__restrict__ tiles;
     DevCounters *__restrict__ ctr;
     GridParams g;
-    uint32_t tiles_cap;
+    uint32_t tiles_cap;   // entries of the last class's segment (any number of tiles a frame can have)
+    uint32_t tile_seg;    // entries of every other class's segment
     const uint2 *__restrict__ row_bounds;
     float4 *__restrict__ normals4;
     int32_t *__restrict__ counts;
@@ -1560,6 +1575,39 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
 // so that runs of xcd_chunk consecutive blocks land on ONE XCD (a sorted row is then fetched into one L2 instead of
 // all eight), runs are dealt round-robin; the tail that does not fill 8 runs keeps the plain order.
 constexpr int kWaveLdsBytes = (kMxWaveLdsBytes + 15) / 16 * 16;
+
+// The tile list as k_normals walks it: class 0 (the costliest tiles) first.  A frame's tiles take 22-52 us each and the
+// chip holds 4 096 of them at a time; in the order they were cut -- position order -- the long ones that happen to come
+// last drain for 40 us over a mostly empty chip.  pre[c] = tiles in classes before c (scalar registers: the counters are
+// read with scalar loads).
+struct TileList {
+    uint32_t n;
+    uint32_t pre[kTileClasses];
+};
+__device__ __forceinline__ TileList tile_list(const NormalsArgs &A)
+{
+    TileList L;
+    uint32_t run = 0;
+#pragma unroll
+    for (int c = 0; c < kTileClasses; ++c) {
+        uint32_t k = A.ctr->n_tiles_c[c][0];
+        const uint32_t cap = c + 1 < kTileClasses ? A.tile_seg : A.tiles_cap;
+        if (k > cap) k = cap;   // (a full segment: its further tiles were filed in the last class)
+        L.pre[c] = run;
+        run += k;
+    }
+    L.n = run;
+    return L;
+}
+__device__ __forceinline__ uint2 tile_at(const NormalsArgs &A, const TileList &L, uint32_t v)   // v < L.n, wave-uniform
+{
+    uint32_t c = 0, first = 0;
+#pragma unroll
+    for (int k = 1; k < kTileClasses; ++k)
+        if (v >= L.pre[k]) { c = (uint32_t)k; first = L.pre[k]; }
+    return A.tiles[(size_t)c * A.tile_seg + (v - first)];
+}
+
 __device__ __forceinline__ uint32_t normals_wave_id(const NormalsArgs &A, uint32_t ntiles)
 {
     uint32_t vblock = blockIdx.x;
@@ -1579,11 +1627,11 @@ __device__ __forceinline__ uint32_t normals_wave_id(const NormalsArgs &A, uint32
 __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals_m(NormalsArgs A, uint32_t mx_min_candidates)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][kWaveLdsBytes];
-    uint32_t ntiles = A.ctr->n_tiles;   // final before the launch (k_rows_and_tiles)
-    if (ntiles > A.tiles_cap) ntiles = A.tiles_cap;
+    const TileList L = tile_list(A);   // final before the launch (k_rows_and_tiles)
+    const uint32_t ntiles = L.n;
     const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
     for (uint32_t t = wave_id; t < ntiles; t += n_waves)   // every wave reaches the end: the list is final
-        normals_tile_mx(A, lds[threadIdx.x / kWave], A.tiles[t], mx_min_candidates);
+        normals_tile_mx(A, lds[threadIdx.x / kWave], tile_at(A, L, t), mx_min_candidates);
 }
 
 // THE production kernel: distances AND moments on the matrix cores (k_normals_m = GM_NORMALS_IMPL=auto0 keeps the
@@ -1602,8 +1650,8 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs
 #else
     const unsigned long long stat_entry = 0ull;
 #endif
-    uint32_t ntiles = A.ctr->n_tiles;
-    if (ntiles > A.tiles_cap) ntiles = A.tiles_cap;
+    const TileList L = tile_list(A);
+    const uint32_t ntiles = L.n;
     const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
     // (the grid is sized for the most tiles a frame of this size can have: most of its waves find no tile and leave here)
     if (wave_id >= ntiles) return;
@@ -1614,11 +1662,11 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs
         uint4 *z = reinterpret_cast<uint4 *>(lds[wv]);
         for (int i = lane_id(); i < kMdWaveLdsBytes / 16; i += kWave) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    normals_tile_mxd<FINE>(A, lds[wv], A.tiles[wave_id], mx_min_candidates, stat_entry);
+    normals_tile_mxd<FINE>(A, lds[wv], tile_at(A, L, wave_id), mx_min_candidates, stat_entry);
 #ifndef GM_NORMALS_NO_LOOP   // (experiment: the kernel without its looped copy -- frames with more tiles than waves unsupported)
     if (ntiles > n_waves && wave_id != 0xFFFFFFFFu)
         for (uint32_t t = wave_id + n_waves; t < ntiles; t += n_waves)
-            normals_tile_mxd<FINE>(A, lds[wv], A.tiles[t], mx_min_candidates);
+            normals_tile_mxd<FINE>(A, lds[wv], tile_at(A, L, t), mx_min_candidates);
 #endif
 }
 
@@ -1626,10 +1674,10 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs
 __global__ __launch_bounds__(kNrThreads) void k_normals_valu(NormalsArgs A)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][(kValuWaveLdsBytes + 15) / 16 * 16];
-    uint32_t ntiles = A.ctr->n_tiles;
-    if (ntiles > A.tiles_cap) ntiles = A.tiles_cap;
+    const TileList L = tile_list(A);
+    const uint32_t ntiles = L.n;
     const uint32_t wave_id = normals_wave_id(A, ntiles), n_waves = gridDim.x * kNrWaves;
-    for (uint32_t t = wave_id; t < ntiles; t += n_waves) normals_tile_valu(A, lds[threadIdx.x / kWave], A.tiles[t]);
+    for (uint32_t t = wave_id; t < ntiles; t += n_waves) normals_tile_valu(A, lds[threadIdx.x / kWave], tile_at(A, L, t));
 }
 
 uint32_t max_tiles(uint32_t n_cap, const GridParams &g)
@@ -1660,7 +1708,7 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     if (!scratch_cleared) hipMemsetAsync(sl.row_bounds, 0, sizeof(uint2) * (size_t)g.ny * (size_t)g.nz, s);
     hipLaunchKernelGGL(k_rows_and_tiles, dim3(2u * ((n_cap + kTbSpan - 1) / kTbSpan)), dim3(kTbThreads), 0, s,
                        (const float4 *)sl.crop4, (const uint32_t *)perm, (const uint32_t *)skeys, sl.ctr, (uint32_t)g.nx,
-                       (uint32_t)(kTileSpan * (g.xreach - 1)), sl.spts4, sl.row_bounds, sl.tiles, sl.tiles_cap);
+                       (uint32_t)(kTileSpan * (g.xreach - 1)), sl.spts4, sl.row_bounds, sl.tiles, sl.tiles_cap, sl.tile_seg);
     // one wave per tile: four tiles per block
     // A wave per tile for twice the tiles of a dense frame (n / 64: full 64-point tiles); a frame with more -- sparse rows
     // cut into many short tiles, at most max_tiles() -- has the rest walked by the kernel's second, looped copy of the
@@ -1687,7 +1735,7 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
     VoxDense vdx = vd;
     vdx.xcd_chunk = xc ? (uint32_t)atoi(xc) : 32u;
     NormalsArgs na;
-    na.spts4 = sl.spts4; na.skeys = skeys; na.tiles = sl.tiles; na.ctr = sl.ctr; na.g = g; na.tiles_cap = sl.tiles_cap;
+    na.spts4 = sl.spts4; na.skeys = skeys; na.tiles = sl.tiles; na.ctr = sl.ctr; na.g = g; na.tiles_cap = sl.tiles_cap; na.tile_seg = sl.tile_seg;
     na.row_bounds = sl.row_bounds; na.normals4 = sl.normals4; na.counts = keep_counts ? sl.counts : (int32_t *)nullptr;
     na.vd = vdx; na.vox_table = sl.vox_table;
     // GM_NORMALS_IMPL: auto (default) = moments on the matrix cores except for thin neighbourhoods (fewer than
@@ -1714,7 +1762,14 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
 extern "C" int gm_debug_counters(gm_ctx *ctx, uint32_t slot, uint32_t *out)
 {
     hipDeviceSynchronize();
-    return (int)hipMemcpy(out, ctx->slots[slot].ctr, sizeof(gm::DevCounters), hipMemcpyDeviceToHost);
+    gm::DevCounters c;
+    const int rc = (int)hipMemcpy(&c, ctx->slots[slot].ctr, sizeof(c), hipMemcpyDeviceToHost);
+    // out[0..18): the counters up to pad[]; out[2] = number of tiles (sum over the cost classes; full segments overflow into
+    // the last class and are counted there a second time -- none in the frames the diagnostics run on)
+    memcpy(out, &c, 18 * sizeof(uint32_t));
+    out[2] = 0;
+    for (int k = 0; k < gm::kTileListClasses; ++k) out[2] += c.n_tiles_c[k][0];
+    return rc;
 }
 #endif
 

@@ -16,7 +16,7 @@ while [ $# -ge 2 ]; do
   (
     objs=""
     for f in gm_api k_crop k_sort k_normals k_frame k_voxel k_ransac k_nearest gm_ext gm_group; do
-      if [ $f = $FILE ] || { [ $FILE = all ] && [ $f != k_normals ] && [ $f != k_nearest ] && [ $f != gm_group ]; }; then
+      if [ $f = $FILE ] || [ $FILE = all ]; then
         /opt/rocm/bin/hipcc $FLAGS $extra -c $SRC/$f.hip -o $OUT/${f}_$tag.o
         objs="$objs $OUT/${f}_$tag.o"
       else objs="$objs $SRC/$f.o"; fi
