@@ -399,16 +399,6 @@ __device__ __forceinline__ bool emit_normal(bool active, const float4 q, const d
         if (!vox_ok) out = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
         normals4[dst] = out;
         if (counts) counts[dst] = cnt;
-#ifdef GM_NORMALS_TIMELINE  // diagnostic build (tools/tile_timeline.py): lanes 0 / 1 of a tile report its end tick / duration
-        {
-            const unsigned long long t1 = wall_clock64();
-            const int lane = lane_id();
-            if (counts && qn >= 2 && lane == 0) counts[dst] = -(int)((t1 & 0x1FFFFFFFull) | 0x20000000ull);  // end tick, bit 29 set
-            if (counts && qn >= 2 && lane == 1) counts[dst] = -(int)((t1 - stat_t0) & 0xFFFFFull) - 1;        // duration < 2^20 ticks
-            // lane 2: ticks between the wave's first instruction and the start of its tile (bit 28 marks it)
-            if (counts && qn >= 3 && lane == 2 && stat_entry) counts[dst] = -(int)(((stat_t0 - stat_entry) & 0xFFFFFull) | 0x10000000ull);
-        }
-#endif
     }
     return vox_ok;
 }
@@ -1057,6 +1047,10 @@ __device__ __forceinline__ s4 md_tr_read(const unsigned char *p)
 #ifndef GM_NORMALS_PREFETCH
 #define GM_NORMALS_PREFETCH 1   // 0: a chunk's rows are loaded when the chunk is staged (A/B measurements)
 #endif
+#ifdef GM_NORMALS_TIMELINE  // diagnostic build (tools/tile_timeline.py): per wave of the straight-line copy, 100 MHz ticks of its first
+                            // instruction, of the moment it knows its tile, and of its end
+__device__ unsigned long long gm_tl_buf[3 * 65536];
+#endif
 #ifdef GM_NORMALS_PHASES   // diagnostic build (tools/normals_phases.py): shader-clock ticks a wave spends in each part of a tile
 __device__ unsigned long long gm_phase_ticks[16];
 #define GM_PH_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -1646,7 +1640,9 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kNrWaves][(kMdWaveLdsBytes + 15) / 16 * 16];
 #ifdef GM_NORMALS_TIMELINE
-    const unsigned long long stat_entry = wall_clock64();
+    // (the very first instruction of the wave: an asm the compiler may not move the kernel-argument loads above)
+    unsigned long long stat_entry;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stat_entry) : : "memory");
 #else
     const unsigned long long stat_entry = 0ull;
 #endif
@@ -1662,7 +1658,19 @@ __global__ __launch_bounds__(kNrThreads, GM_MX_WAVES) void k_normals(NormalsArgs
         uint4 *z = reinterpret_cast<uint4 *>(lds[wv]);
         for (int i = lane_id(); i < kMdWaveLdsBytes / 16; i += kWave) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
+#ifdef GM_NORMALS_TIMELINE
+    const uint2 tile_tl = tile_at(A, L, wave_id);
+    unsigned long long stat_tile;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stat_tile) : "v"(tile_tl.x) : "memory");   // (after the tile's load has returned)
+    normals_tile_mxd<FINE>(A, lds[wv], tile_tl, mx_min_candidates, stat_entry);
+    if (wave_id < 65536u && lane_id() == 0) {
+        gm_tl_buf[3 * wave_id + 0] = stat_entry;
+        gm_tl_buf[3 * wave_id + 1] = stat_tile;
+        gm_tl_buf[3 * wave_id + 2] = (unsigned long long)wall_clock64();
+    }
+#else
     normals_tile_mxd<FINE>(A, lds[wv], tile_at(A, L, wave_id), mx_min_candidates, stat_entry);
+#endif
 #ifndef GM_NORMALS_NO_LOOP   // (experiment: the kernel without its looped copy -- frames with more tiles than waves unsupported)
     if (ntiles > n_waves && wave_id != 0xFFFFFFFFu)
         for (uint32_t t = wave_id + n_waves; t < ntiles; t += n_waves)
@@ -1770,6 +1778,16 @@ extern "C" int gm_debug_counters(gm_ctx *ctx, uint32_t slot, uint32_t *out)
     out[2] = 0;
     for (int k = 0; k < gm::kTileListClasses; ++k) out[2] += c.n_tiles_c[k][0];
     return rc;
+}
+#endif
+
+#ifdef GM_NORMALS_TIMELINE
+// diagnostic builds only: (entry, tile known, end) ticks of the first n waves of the last k_normals launch
+extern "C" int gm_debug_timeline(unsigned long long *out, uint32_t n)
+{
+    hipDeviceSynchronize();
+    if (n > 65536u) n = 65536u;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gm::gm_tl_buf), sizeof(unsigned long long) * 3 * (size_t)n);
 }
 #endif
 
