@@ -218,6 +218,7 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
     // any real frame; a full one overflows into the last) + one that holds every tile a frame can have (>= 1 point each)
     sl.tiles_cap = cap + 2u;
     sl.tile_seg = cap / (uint32_t)kTileListClasses + 2u;
+    if (const char *e = getenv("GM_TEST_TILE_SEG")) sl.tile_seg = (uint32_t)(atoi(e) > 0 ? atoi(e) : 1);   // tests: force the overflow path
     GM_HIP(ctx, dmalloc(sl.tiles, (size_t)(kTileListClasses - 1) * sl.tile_seg + sl.tiles_cap));
     GM_HIP(ctx, dmalloc(sl.row_bounds, (size_t)1024 * 1024));  // make_grid caps every axis at 1024 cells
     sl.blk_cap = compact_records(cap > kVoxDenseMaxCells ? cap : kVoxDenseMaxCells) + 1;

@@ -457,6 +457,41 @@ def test_normals_grid_stride_path_is_bitwise_identical(gm):
         assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
 
 
+@pytest.mark.parametrize("seg", [None, "3"])
+def test_tile_list_class_overflow_keeps_every_tile(gm, oc, seg, monkeypatch):
+    """k_normals walks its tiles by cost class (x extent); every class but the last has room for capacity / 8 tiles and a
+    full one overflows into the last (k_rows_and_tiles, csrc/k_normals.hip).  A lattice cloud whose rows hold one point
+    every 1.2 r is cut into tiles of two or three points with two extents only: far more tiles per class than a segment
+    holds (and with GM_TEST_TILE_SEG=3, read when a context sizes its buffers, every class of any frame overflows).
+    Every point must still get its neighbours (counts bit-exact) and its normal."""
+    if seg:
+        monkeypatch.setenv("GM_TEST_TILE_SEG", seg)
+    else:
+        monkeypatch.delenv("GM_TEST_TILE_SEG", raising=False)
+    from geometric_mapping_amd import _lib
+    r = 0.25
+    ax = np.arange(-4.8, 4.8, 1.2 * r, dtype=np.float32)
+    ay = np.arange(-1.0, 1.0, 0.9 * r, dtype=np.float32)
+    X, Y, Z = np.meshgrid(ax, ay, ay, indexing="ij")
+    rng = np.random.default_rng(5)
+    xyz = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1).astype(np.float32)
+    xyz += rng.normal(0, 0.01, xyz.shape).astype(np.float32)          # (no exactly coplanar neighbourhoods)
+    xyz = xyz[rng.permutation(len(xyz))]
+    with gm.GeometricMapping(boxFilterBound=5.0, neighborRadius=r, flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_KEEP_COUNTS,
+                             max_points=len(xyz)) as c:
+        res = c.process_frame(xyz)
+        cnt = c.neighbor_counts()
+        nrm = c.normals()
+    keep = oc.crop_box(xyz, 5.0)
+    o_n, o_cnt = oc.normals(xyz[keep], r, oc.F64)
+    assert res["n_cropped"] == len(keep) == len(xyz)
+    assert np.array_equal(cnt, o_cnt)
+    valid = oc.finite_normals(o_n)
+    assert res["n_valid"] == len(valid)
+    s = np.linalg.norm(np.cross(nrm[:, :3].astype(np.float64), o_n[valid][:, :3].astype(np.float64)), axis=1)
+    assert np.quantile(np.arcsin(np.clip(s, 0, 1)), 0.999) < 1e-5
+
+
 def test_chained_scan_epochs_wrap_cleanly(gm):
     """The chained scans tag their records with an epoch that wraps (host counter: every 2^29 - 2 launches of a slot;
     replayed graphs: every 2^26 frames).  At the wrap the record array is cleared so that no record of the previous
