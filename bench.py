@@ -57,7 +57,8 @@ def parse():
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--radius", type=float, default=None, help="default: fixed-k 0.5*sqrt(50000/points)")
     ap.add_argument("--mode", choices=("frames", "slab"), default="frames")
-    ap.add_argument("--slots", type=int, default=3, help="frames in flight per GPU (HIP streams)")
+    ap.add_argument("--slots", type=int, default=4, help="frames in flight per GPU (HIP streams; 4 is the measured best once every "
+                    "stream has a hardware queue of its own: GPU_MAX_HW_QUEUES below)")
     ap.add_argument("--ransac", type=int, default=1,
                     help="1: the step includes ONE RANSAC model (cylinder, H=1024: BASELINE configs[1]); 0: reference-faithful path only")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra reference-faithful / host-input legs")
@@ -162,6 +163,10 @@ def cpu_config1(threads):
 
 def main():
     args = parse()
+    # ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with the frames' streams
+    # plus the runtime's own, a fourth frame in flight shares a queue with another and is serialised behind it (measured:
+    # 4 slots 0.271 ms per step with 4 queues, 0.211 with 8; 3 slots 0.227 either way).  Read when the runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -324,9 +329,16 @@ def main():
         k_ms_excl = float(np.mean(ex[2:]))
     if not args.no_secondary and world == 1:
         if ransac_on:  # the reference-faithful path alone (no extension work in the step)
-            with make_ctx(_lib.GM_CFG_DEFAULT, n_slots) as c2:
-                dt2, _ = timed(c2, clouds, n_slots)
-            secondary["reference_faithful_path_only"] = {"value": n * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3}
+            # (its shorter chain overlaps differently: measured with the step's number of slots and with one less)
+            rows = {}
+            for sl in sorted({n_slots, max(1, n_slots - 1)}):
+                with make_ctx(_lib.GM_CFG_DEFAULT, sl) as c2:
+                    dt2, _ = timed(c2, clouds, sl)
+                rows[sl] = dt2
+            best = min(rows, key=rows.get)
+            secondary["reference_faithful_path_only"] = {"value": n * args.steps / rows[best], "ms_per_step": rows[best] / args.steps * 1e3,
+                                                         "frames_in_flight": best,
+                                                         "ms_per_step_by_frames_in_flight": {str(k): v / args.steps * 1e3 for k, v in rows.items()}}
         # per-stage device times of one frame alone (events on; outside every timed region)
         with make_ctx(flags | _lib.GM_CFG_STAGE_TIMING, 1) as c3:
             for _ in range(3):
@@ -471,7 +483,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n}-pt synthetic tunnel frame (R=2 m, L=12 m, sigma=0.01), rows resident in HBM",
                        "neighborRadius": radius, "k_regime": "fixed-k (~256 neighbours)", "boxFilterBound": bound,
-                       "voxelGridLeafSize": leaf, "weightingFactor": wf, "mode": mode, "frames_in_flight": n_slots,
+                       "voxelGridLeafSize": leaf, "weightingFactor": wf, "mode": mode, "frames_in_flight": n_slots, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "ransac_model": "cylinder, H=1024, tau=0.03 (extension)" if ransac_on else "none (reference-faithful path)",
                        "parallelism": f"{mode}x{world}", "collective_backend": args.dist_backend if world > 1 else None},
             "roofline": {"kernel": "k_normals",
