@@ -63,7 +63,7 @@ struct CropEmit {
     GridParams g;
     float4 *__restrict__ crop4;
     uint32_t *__restrict__ keys;
-    // (The keys leave as one dword per lane, 256 bytes per store instruction; tools/microbench_stream.hip prices those 33 MB
+    // (The keys leave as one dword per lane, 256 bytes per store instruction; tools/microbench/stream_probe.hip prices those 33 MB
     // of the 10 M-point frame at 14 us, as much as 80 MB of 16-byte-per-lane stores.  Collecting a wave's keys in LDS --
     // its survivors are consecutive in the output -- and writing them 16 bytes per lane was measured: 80 -> 86 us, the
     // stores then wait for the wave's last item.)
@@ -112,7 +112,7 @@ void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const Gr
     // wants the small one (17.5 against 21 us for 512 x 16).  Measured around it at 10 M points: 512x16 89 us, 512x24
     // 86, 512x32 116, 1024x12 85, 1024x16 91, 256x32 100, 512x4 and 256x8 143; MORE resident blocks per CU are slower
     // (1024x8 held to 64 registers, two blocks per CU: 103 us; 512x16 at three per CU: 91), fewer too (512x8, one per
-    // CU: 131).  What the pattern allows without any scan: tools/microbench_stream.hip, 66-74 us.
+    // CU: 131).  What the pattern allows without any scan: tools/microbench/stream_probe.hip, 66-74 us.
     // GM_CROP_TILE=<threads>x<items>: experiments.
     static const char *e = getenv("GM_CROP_TILE");
     int th = 512, it = 8;

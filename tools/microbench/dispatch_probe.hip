@@ -1,5 +1,5 @@
 // microbench_dispatch.hip -- how fast does the chip fill with waves of a given shape?
-// Standalone (hipcc --offload-arch=gfx950 -O3 tools/microbench_dispatch.hip -o build/microbench_dispatch); run on the GPU box.
+// Standalone (hipcc --offload-arch=gfx950 -O3 tools/microbench/dispatch_probe.hip -o build/dispatch_probe); run on the GPU box.
 // Every wave stamps the 100 MHz wall clock at its first instruction, then spins for ~SPIN us so that the first
 // 4 096 waves (256 CUs x 16) are all resident while the fill is observed.  Shapes: registers per lane (64 / 128, by
 // launch bounds and a live array), LDS per block (0 / 10 / 40 KB), scratch (a runtime-indexed private array), block

@@ -1,5 +1,5 @@
 // microbench_stream.hip -- what bounds a "read 16-byte rows, write the survivors" stream on this chip?
-// Standalone (hipcc --offload-arch=gfx950 -O3 tools/microbench_stream.hip -o build/microbench_stream); run on the GPU box.
+// Standalone (hipcc --offload-arch=gfx950 -O3 tools/microbench/stream_probe.hip -o build/stream_probe); run on the GPU box.
 // Variants of one 10 M-row pass (160 MB in), timed with hipEvents, best and median of 20:
 //   copy        grid-stride float4 copy (the guide's 6.29 TB/s shape)
 //   tile        512-thread blocks, ITEMS rows per thread loaded first, then stored to the same index (the compaction's phases)
