@@ -1,4 +1,4 @@
-// microbench_dispatch.hip -- how fast does the chip fill with waves of a given shape?
+// dispatch_probe.hip -- how fast does the chip fill with waves of a given shape?
 // Standalone (hipcc --offload-arch=gfx950 -O3 tools/microbench/dispatch_probe.hip -o build/dispatch_probe); run on the GPU box.
 // Every wave stamps the 100 MHz wall clock at its first instruction, then spins for ~SPIN us so that the first
 // 4 096 waves (256 CUs x 16) are all resident while the fill is observed.  Shapes: registers per lane (64 / 128, by

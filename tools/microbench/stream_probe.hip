@@ -1,4 +1,4 @@
-// microbench_stream.hip -- what bounds a "read 16-byte rows, write the survivors" stream on this chip?
+// stream_probe.hip -- what bounds a "read 16-byte rows, write the survivors" stream on this chip?
 // Standalone (hipcc --offload-arch=gfx950 -O3 tools/microbench/stream_probe.hip -o build/stream_probe); run on the GPU box.
 // Variants of one 10 M-row pass (160 MB in), timed with hipEvents, best and median of 20:
 //   copy        grid-stride float4 copy (the guide's 6.29 TB/s shape)
