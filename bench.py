@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this device")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--graph", type=int, default=0, help="1: the timed contexts replay their launch chains from captured hipGraphs (GM_CFG_GRAPH)")
+    ap.add_argument("--distinct-frames", type=int, default=5, help="synthetic frames the stream cycles through (not a multiple of "
+                    "--slots: a slot must not see the same frame every time)")
     ap.add_argument("--frames", type=int, default=24, help="frames of the per-frame (blocking, H2D-inclusive) protocol")
     ap.add_argument("--profile-tag", default=None, help="rNN prefix of the profiles/ files to quote (default: newest)")
     ap.add_argument("--group-points", type=int, default=10_000_000,
@@ -216,7 +218,7 @@ def main():
     n_slots = max(1, args.slots)
     mode = args.mode if world > 1 else "frames"
     if mode == "frames":
-        n_frames = 4
+        n_frames = max(1, args.distinct_frames)
         frames_host = [synth.tunnel_frame(n, seed=1000 * rank + s) for s in range(n_frames)]
         dev = [torch.from_numpy(rows16(f)).cuda() for f in frames_host]
         pts_per_step_rank = n
