@@ -43,12 +43,13 @@ void free_slot_buffers(Slot &sl)
 {
     hipFree(sl.d_raw); hipFree(sl.crop4); hipFree(sl.keys_a); hipFree(sl.keys_b); hipFree(sl.vals_a);
     hipFree(sl.vals_b); hipFree(sl.spts4); hipFree(sl.normals4); hipFree(sl.counts); hipFree(sl.valid4);
-    hipFree(sl.vnorm4); hipFree(sl.tiles); hipFree(sl.row_bounds); hipFree(sl.blk); hipFree(sl.tile_partials); hipFree(sl.sort.hist); hipFree(sl.seg_start);
+    hipFree(sl.vnorm4); hipFree(sl.tiles); hipFree(sl.row_bounds); hipFree(sl.blk); hipFree(sl.tile_partials); hipFree(sl.sort.totals); hipFree(sl.sort.rec);
+    hipFree(sl.sort.ticket); hipFree(sl.tile_rec); hipFree(sl.seg_start);
     hipFree(sl.vox4); hipFree(sl.vox_nn); hipFree(sl.labels);
     if (sl.h_raw) hipHostFree(sl.h_raw);
     sl.d_raw = nullptr; sl.h_raw = nullptr; sl.crop4 = nullptr; sl.keys_a = sl.keys_b = sl.vals_a = sl.vals_b = nullptr;
     sl.spts4 = sl.normals4 = sl.valid4 = sl.vnorm4 = sl.vox4 = nullptr; sl.counts = nullptr; sl.tiles = nullptr; sl.row_bounds = nullptr;
-    sl.blk = nullptr; sl.tile_partials = nullptr; sl.sort.hist = nullptr; sl.seg_start = nullptr; sl.vox_nn = nullptr; sl.labels = nullptr;
+    sl.blk = nullptr; sl.tile_partials = nullptr; sl.sort = SortScratch{}; sl.tile_rec = nullptr; sl.tile_rec_words = 0; sl.seg_start = nullptr; sl.vox_nn = nullptr; sl.labels = nullptr;
     sl.cap = 0; sl.raw_cap = 0; sl.tiles_cap = 0; sl.tile_seg = 0;
 }
 
@@ -214,11 +215,10 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
     GM_HIP(ctx, dmalloc(sl.valid4, cap)); GM_HIP(ctx, dmalloc(sl.vnorm4, cap));
     GM_HIP(ctx, dmalloc(sl.seg_start, cap)); GM_HIP(ctx, dmalloc(sl.vox4, cap));
     GM_HIP(ctx, dmalloc(sl.vox_nn, cap)); GM_HIP(ctx, dmalloc(sl.labels, cap));
-    // tile list: kTileListClasses - 1 segments for the tiles with an x extent (>= 2 points each, a few per cent of cap in
-    // any real frame; a full one overflows into the last) + one that holds every tile a frame can have (>= 1 point each)
+    // tile list: kTileListClasses - 1 segments for the tiles with an x extent (>= 2 points each: none of them can hold more
+    // than cap / 2 tiles) + one that holds every tile a frame can have (>= 1 point each).  No list can overflow.
     sl.tiles_cap = cap + 2u;
-    sl.tile_seg = cap / (uint32_t)kTileListClasses + 2u;
-    if (const char *e = getenv("GM_TEST_TILE_SEG")) sl.tile_seg = (uint32_t)(atoi(e) > 0 ? atoi(e) : 1);   // tests: force the overflow path
+    sl.tile_seg = cap / 2u + 2u;
     GM_HIP(ctx, dmalloc(sl.tiles, (size_t)(kTileListClasses - 1) * sl.tile_seg + sl.tiles_cap));
     GM_HIP(ctx, dmalloc(sl.row_bounds, (size_t)1024 * 1024));  // make_grid caps every axis at 1024 cells
     sl.blk_cap = compact_records(cap > kVoxDenseMaxCells ? cap : kVoxDenseMaxCells) + 1;
@@ -230,8 +230,15 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
         static const char *e = getenv("GM_TEST_SCAN_EPOCH");
         sl.scan_epoch = e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
     }
-    sl.sort.hist_cap = radix_hist_entries(cap);
-    GM_HIP(ctx, dmalloc(sl.sort.hist, sl.sort.hist_cap));
+    // radix sort scratch: digit totals, the passes' record array (both cleared per sort) and the ticket words (zeroed once)
+    GM_HIP(ctx, dmalloc(sl.sort.totals, radix_totals_bytes() / sizeof(uint32_t)));
+    sl.sort.rec_words = (radix_record_words_max(cap) + 1u) & ~(size_t)1u;
+    GM_HIP(ctx, dmalloc(sl.sort.rec, sl.sort.rec_words));
+    GM_HIP(ctx, dmalloc(sl.sort.ticket, 4));
+    GM_HIP(ctx, hipMemsetAsync(sl.sort.ticket, 0, 16, sl.stream));
+    sl.tile_rec_words = (size_t)(tile_cutter_blocks(cap) + 1) * (size_t)kTileListClasses;
+    GM_HIP(ctx, dmalloc(sl.tile_rec, sl.tile_rec_words));
+    GM_HIP(ctx, hipMemsetAsync(sl.tile_rec, 0, sizeof(unsigned long long) * sl.tile_rec_words, sl.stream));
     sl.cap = cap;
     ++sl.alloc_gen;
     return GM_OK;
@@ -329,11 +336,14 @@ static gm_status enqueue_launches(gm_ctx *ctx, Slot &sl, const RowLayout &rows, 
         z.ptr[0] = sl.ctr; z.words8[0] = sizeof(DevCounters) / 8;
         if (vd.enabled) { z.ptr[1] = sl.vox_table; z.words8[1] = (uint64_t)vd.dim * vd.dim * vd.dim * sizeof(VoxCell) / 8; }
         if (sl.row_bounds) { z.ptr[2] = sl.row_bounds; z.words8[2] = (uint64_t)g.ny * (uint64_t)g.nz; }  // (no buffers yet
-        if (sl.sort.hist) { z.ptr[3] = sl.sort.hist; z.words8[3] = radix_totals_bytes() / 8; }           //  before the first non-empty frame)
+        if (sl.sort.totals) {                                                                            //  before the first non-empty frame)
+            z.ptr[3] = sl.sort.totals; z.words8[3] = radix_totals_bytes() / 8;
+            z.ptr[4] = sl.sort.rec; z.words8[4] = (radix_record_words(ns, cell_key_bits(g)) + 1) / 2;   // records of the cell sort's chained scans
+        }
         z.frame_counter = sl.frame_in + 1;
         launch_zero_fill(z, s);
     }
-    launch_crop(rows, n, lo, hi, g, sl, s, ns, n_dev);
+    launch_crop(rows, n, lo, hi, g, sl, s, ns, n_dev, true);   // (also counts the digit totals of the cell sort)
     record(ctx, sl, 2);
     launch_grid_and_normals(g, vd, sl, ns, (cf.flags & GM_CFG_KEEP_COUNTS) != 0, true, s);
     record(ctx, sl, 3);  // end of grid+normals; the kernel alone is bracketed by ev_k0/ev_k1
@@ -387,11 +397,13 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     }
     hipStream_t s = sl.stream;
     sl.n_in = n;
-    // Epochs of replayed (graph) scans are (frame counter * 8 + launch index) mod 2^29: they repeat every 2^26 frames of
+    // Epochs of replayed (graph) scans are (frame counter * 32 + launch index) mod 2^29: they repeat every 2^24 frames of
     // the slot.  Twice per period the records are cleared between two frames (all of them are stale there), so that a
     // record can never be as old as a period.
-    if ((++sl.frames_enqueued & 0x1FFFFFFu) == 0u && sl.blk)
+    if ((++sl.frames_enqueued & 0x7FFFFFu) == 0u && sl.blk) {
         GM_HIP(ctx, hipMemsetAsync(sl.blk, 0, sizeof(unsigned long long) * (size_t)sl.blk_cap, s));
+        GM_HIP(ctx, hipMemsetAsync(sl.tile_rec, 0, sizeof(unsigned long long) * sl.tile_rec_words, s));
+    }
     record(ctx, sl, 0);
     const uint8_t *dev_rows = (const uint8_t *)cloud->data;
     if (!on_dev && n) {

@@ -50,7 +50,9 @@ inline uint32_t compact_grid(uint32_t n) { return compact_blocks(n); }          
 //       __device__ bool operator()(uint32_t i, Payload &p) const
 // Emit: __device__ void operator()(uint32_t src, uint32_t dst, const Payload &p); static constexpr bool kHasFinish; when true,
 //       __device__ void finish(uint32_t tile) is called by every thread of the block once per tile that held input,
-//       after the tile's last emit (per-tile state lives in the functor; finish() resets it)
+//       after the tile's last emit (per-tile state lives in the functor; finish() resets it); static constexpr bool
+//       kHasPrepare; when true, __device__ void prepare() is called by every thread as the block starts (block-shared
+//       state of the emit step; a block barrier follows before the first emit)
 // The element count is *n_ptr (device-resident) or n_host; the grid is compact_grid(capacity): a block per tile.  The number of survivors
 // goes to total_out / total_out2 (either may be null) -- also when it is 0.
 template <class Pred, class Emit, int THREADS = kCpThreads, int ITEMS = kCpItems>
@@ -76,6 +78,7 @@ __global__ __launch_bounds__(THREADS) void k_compact(Pred pred, Emit emit, const
         return;
     }
     __shared__ uint32_t s_tile;
+    if constexpr (Emit::kHasPrepare) emit.prepare();
 #ifdef GM_CP_DIAG_NOTICKET   // timing diagnostic only (tools/build_variants.sh): what the ticket costs
     if (threadIdx.x == 0) s_tile = blockIdx.x;
 #else

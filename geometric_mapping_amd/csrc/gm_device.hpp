@@ -26,7 +26,7 @@ struct ScanState {
 // [2^29, 2^30): the two ranges never meet, so records of the one kind are never taken for records of the other.
 __device__ __forceinline__ uint32_t scan_epoch(const ScanState &st)
 {
-    return st.frame_ptr ? 0x20000000u + (((*st.frame_ptr) * 8u + st.epoch) & 0x1FFFFFFFu) : st.epoch;
+    return st.frame_ptr ? 0x20000000u + (((*st.frame_ptr) * 32u + st.epoch) & 0x1FFFFFFFu) : st.epoch;
 }
 
 #ifndef GM_TILE_CLASSES

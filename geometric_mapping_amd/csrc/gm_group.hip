@@ -785,7 +785,10 @@ gm_status gm_group_submit_frame(gm_group *grp, const gm_cloud *cloud)
         for (const gm_group::Ticket &t : G.inflight) used += t.rank == r ? 1u : 0u;
         if (used >= G.ctx[r]->n_slots) continue;
         const uint32_t slot = G.next_slot[r];
-        if (G.have_frame || G.ctx[r]->own_lo != -std::numeric_limits<double>::infinity()) {
+        // a sharded frame (also one that failed half-way) leaves the ranks with slab ranges: rank 0 owns (-inf, edge[1]),
+        // so BOTH ends have to be looked at -- a streamed frame is a whole frame, every point of it is the rank's own
+        if (G.ctx[r]->own_lo != -std::numeric_limits<double>::infinity() ||
+            G.ctx[r]->own_hi != std::numeric_limits<double>::infinity()) {
             const gm_status st = gm_set_owned_range(G.ctx[r], -std::numeric_limits<double>::infinity(), std::numeric_limits<double>::infinity());
             if (st != GM_OK) return gfail(grp, st, gm_last_error(G.ctx[r]));
         }

@@ -22,9 +22,14 @@ struct RowLayout {
 };
 
 struct SortScratch {
-    uint32_t *hist;       // [bins * nblocks]
-    uint32_t hist_cap;
+    uint32_t *totals = nullptr;           // [kRsMaxPasses][2048] digit totals of every pass (zero-filled when a frame opens)
+    uint32_t *rec = nullptr;              // [pass][tile][digit] records of the passes' chained scans (k_sort.hip), cleared per sort
+    size_t rec_words = 0;
+    uint32_t *ticket = nullptr;           // ticket word of the passes (0 between launches); [1]: the tile cutter's
 };
+
+// passes x bits of the radix sort for a key width (k_sort.hip); the crop counts the digit totals of exactly this plan
+struct SortPlan { int passes, bits; };
 
 // One in-flight frame: its stream, staging and device buffers (grow-only).
 struct Slot {
@@ -65,6 +70,8 @@ struct Slot {
     uint64_t graph_clock = 0;
     uint32_t alloc_gen = 0;             // bumped whenever a device buffer of the slot is (re)allocated
     SortScratch sort = {};
+    unsigned long long *tile_rec = nullptr;   // [cutter blocks + 1][kTileListClasses] records of the tile cutter's chained scan
+    size_t tile_rec_words = 0;
     uint32_t *seg_start = nullptr;
     float4 *vox4 = nullptr;       // voxel centroids: x,y,z,count
     VoxCell *vox_table = nullptr; // dense voxel table (fast path)
@@ -101,7 +108,7 @@ inline ScanState next_scan(Slot &sl)
     ScanState st;
     st.status = sl.blk;
     if (sl.capturing) {   // (replayed launches derive their epoch on the device)
-        st.epoch = sl.scan_seq++ & 7u;
+        st.epoch = sl.scan_seq++ & 31u;
         st.frame_ptr = sl.frame_in + 1;
     } else {
         // 1 .. 2^29-2, never 0.  When the counter wraps, the records are cleared (on the slot's stream, behind every
@@ -109,6 +116,7 @@ inline ScanState next_scan(Slot &sl)
         // otherwise carry the epoch that is about to be reused and read as ready.
         if (sl.scan_epoch >= 0x1FFFFFFEu) {
             (void)hipMemsetAsync(sl.blk, 0, sizeof(unsigned long long) * (size_t)sl.blk_cap, sl.stream);
+            if (sl.tile_rec) (void)hipMemsetAsync(sl.tile_rec, 0, sizeof(unsigned long long) * sl.tile_rec_words, sl.stream);
             sl.scan_epoch = 0;
         }
         sl.scan_epoch += 1u;
@@ -138,22 +146,29 @@ constexpr int kScatterBlocks = 1024;
 // ---- launchers (each enqueues on `s`, never synchronises) --------------------
 
 // k_crop.hip
+// count_digits: the emit step also counts the digit totals of the cell sort's passes into sl.sort.totals (which the
+// caller has zeroed on this stream)
 void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const GridParams &g, Slot &sl, hipStream_t s,
-                 uint32_t n_size = 0, const uint32_t *n_dev = nullptr);
-// k_sort.hip : stable LSD radix sort of (key,val) pairs; n is device-resident.
-// Returns 0 if the sorted data ends in (keys_a, vals_a), 1 if in (keys_b, vals_b).
+                 uint32_t n_size = 0, const uint32_t *n_dev = nullptr, bool count_digits = false);
+// k_sort.hip : stable LSD radix sort of (key, index) pairs, one launch per pass; n is device-resident.
+// Returns 0 if the sorted keys (and values) end in (keys_a, vals_a), 1 if in (keys_b, vals_b).
 size_t radix_totals_bytes();
+size_t radix_record_words(uint32_t n_cap, int key_bits);   // record words a sort of n_cap positions uses (cleared before it)
+size_t radix_record_words_max(uint32_t n_cap);
+SortPlan radix_plan(int key_bits);
+int cell_key_bits(const GridParams &g);
 int launch_radix_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b,
-                      const uint32_t *n_ptr, uint32_t n_cap, int key_bits, SortScratch &sc, bool totals_cleared,
-                      hipStream_t s);
-uint32_t radix_hist_entries(uint32_t n_cap);
+                      const uint32_t *n_ptr, uint32_t n_cap, int key_bits, Slot &sl, bool prepared,
+                      hipStream_t s, const float4 *rows_in = nullptr, float4 *rows_out = nullptr);
 // k_normals.hip
+// scratch_cleared: the frame's opening zero-fill cleared the per-row table AND the crop counted the sort's digit totals
 void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, uint32_t n_cap, bool keep_counts,
                              bool scratch_cleared, hipStream_t s);
 // one launch that zero-fills up to four 8-byte-granular regions (the frame's counters and scratch tables)
-struct ZeroJobs { void *ptr[4]; uint64_t words8[4]; uint32_t *frame_counter; };   // (+1 on the counter: one frame more)
+struct ZeroJobs { void *ptr[6]; uint64_t words8[6]; uint32_t *frame_counter; };   // (+1 on the counter: one frame more)
 void launch_zero_fill(const ZeroJobs &jobs, hipStream_t s);
 uint32_t max_tiles(uint32_t n_cap, const GridParams &g);
+uint32_t tile_cutter_blocks(uint32_t n_cap);   // blocks (= chained-scan records per class) of k_rows_and_tiles
 // k_frame.hip
 // NaN-normal compaction; also leaves the scatter-matrix partial rows of the survivors in sl.tile_partials (one per
 // kCpTile cropped points); returns the number of rows launched

@@ -57,12 +57,43 @@ struct CropPred {
     }
 };
 
+// digit counters of the block: [pass][bin] for the passes of the cell sort (k_sort.hip radix_plan)
+__device__ __forceinline__ uint32_t *crop_digit_hist()
+{
+    __shared__ uint32_t h[4 << 10];
+    return h;
+}
+
 struct CropEmit {
-    static constexpr bool kHasFinish = false;
+    static constexpr bool kHasFinish = true, kHasPrepare = true;
     RowReader rd;
     GridParams g;
     float4 *__restrict__ crop4;
     uint32_t *__restrict__ keys;
+    // The digit totals of every pass of the cell sort do not depend on the order of the keys, and the keys are in
+    // registers here: the block counts them in LDS as it emits and adds its counts to the totals the sort's passes start
+    // from (plan.passes == 0: not asked for).  The sort then needs no histogram launch at all.
+    SortPlan plan;
+    uint32_t *__restrict__ totals;   // [pass][2048]
+    __device__ __forceinline__ void prepare() const
+    {
+        if (plan.passes) {
+            uint32_t *h = crop_digit_hist();
+            for (uint32_t k = threadIdx.x; k < ((uint32_t)plan.passes << plan.bits); k += blockDim.x) h[k] = 0u;
+        }
+    }
+    __device__ __forceinline__ void finish(uint32_t) const
+    {
+        if (plan.passes) {
+            __syncthreads();   // every emit of the block has counted
+            uint32_t *h = crop_digit_hist();
+            const uint32_t bins = 1u << plan.bits;
+            for (uint32_t k = threadIdx.x; k < ((uint32_t)plan.passes << plan.bits); k += blockDim.x) {
+                const uint32_t c = h[k];
+                if (c) atomicAdd(&totals[(k >> plan.bits) * 2048u + (k & (bins - 1u))], c);
+            }
+        }
+    }
     // (The keys leave as one dword per lane, 256 bytes per store instruction; tools/microbench/stream_probe.hip prices those 33 MB
     // of the 10 M-point frame at 14 us, as much as 80 MB of 16-byte-per-lane stores.  Collecting a wave's keys in LDS --
     // its survivors are consecutive in the output -- and writing them 16 bytes per lane was measured: 80 -> 86 us, the
@@ -70,7 +101,14 @@ struct CropEmit {
     __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst, const CropPred::Payload &p) const
     {
         crop4[dst] = make_float4(p.x, p.y, p.z, __uint_as_float(src));
-        keys[dst] = cell_key(g, p.x, p.y, p.z);
+        const uint32_t key = cell_key(g, p.x, p.y, p.z);
+        keys[dst] = key;
+        if (plan.passes) {
+            uint32_t *h = crop_digit_hist();
+            const uint32_t bins = 1u << plan.bits;
+#pragma unroll 4
+            for (int q = 0; q < plan.passes; ++q) atomicAdd(&h[((uint32_t)q << plan.bits) + ((key >> (q * plan.bits)) & (bins - 1u))], 1u);
+        }
     }
 };
 
@@ -78,7 +116,7 @@ __global__ __launch_bounds__(256) void k_zero_fill(ZeroJobs jobs)
 {
     const uint2 z = make_uint2(0u, 0u);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 6; ++j) {
         uint2 *p = reinterpret_cast<uint2 *>(jobs.ptr[j]);
         const uint64_t nw = jobs.words8[j];
         for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (uint64_t)gridDim.x * blockDim.x) p[i] = z;
@@ -90,7 +128,7 @@ __global__ __launch_bounds__(256) void k_zero_fill(ZeroJobs jobs)
 void launch_zero_fill(const ZeroJobs &jobs, hipStream_t s)
 {
     uint64_t most = 0;
-    for (int j = 0; j < 4; ++j) most = jobs.words8[j] > most ? jobs.words8[j] : most;
+    for (int j = 0; j < 6; ++j) most = jobs.words8[j] > most ? jobs.words8[j] : most;
     uint32_t nb = (uint32_t)((most + 255) / 256);
     if (nb > 1024u) nb = 1024u;
     if (nb == 0) nb = 1;
@@ -99,13 +137,13 @@ void launch_zero_fill(const ZeroJobs &jobs, hipStream_t s)
 
 // n_size >= n sizes the launch; the point count is n, or *n_dev when given (a captured launch: its arguments are frozen)
 void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const GridParams &g, Slot &sl, hipStream_t s,
-                 uint32_t n_size, const uint32_t *n_dev)
+                 uint32_t n_size, const uint32_t *n_dev, bool count_digits)
 {
     if (n_size < n) n_size = n;
     if (n_size == 0) return;  // counters were zeroed: n_cropped stays 0
     RowReader rd{rows};
     CropPred pred{rd, lo, hi};
-    CropEmit emit{rd, g, sl.crop4, sl.keys_a};
+    CropEmit emit{rd, g, sl.crop4, sl.keys_a, count_digits ? radix_plan(cell_key_bits(g)) : SortPlan{0, 0}, sl.sort.totals};
     // Tile shape: 512 threads x 8 rows, and 1024 x 8 for frames beyond 2 M points.  Every tile costs a ticket and a
     // look-back; with every block slot of the chip taken (2.4 rounds of 4096-point tiles at 10 M points) twice the tile
     // is 107 -> 80 us on the 10 M-point frame and 34.5 -> 31 us at 3 M, while the 1 M-point frame (204 tiles for 256 CUs)

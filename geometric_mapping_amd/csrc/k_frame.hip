@@ -65,7 +65,7 @@ __device__ __forceinline__ void scatter_row_store(const double m[6], double *__r
 // leaves one partial row per tile (index = tile, i.e. position order: the rows do not depend on which block ran which
 // tile), so getLocalFrame needs no pass of its own over the compacted normals.
 struct ValidEmit {
-    static constexpr bool kHasFinish = true;
+    static constexpr bool kHasFinish = true, kHasPrepare = false;
     const float4 *__restrict__ crop4;
     float4 *__restrict__ valid4;
     float4 *__restrict__ vnorm4;

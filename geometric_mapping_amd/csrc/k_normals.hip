@@ -96,59 +96,59 @@ constexpr int kWinPad = 16;               // far-away padding behind a chunk (al
 constexpr int kTileSpan = 3;              // max x extent of one tile, in (coarse) cell edges
 constexpr int kNrWaves = kNrThreads / kWave;
 
-// ---- sorted cloud, per-row table and tiles in one launch -------------------------
-// Two roles share the launch (odd / even blocks, so both are in flight together), each block covering kTbSpan sorted
-// positions: odd blocks gather the cropped points into sorted order (a stream of dependent random reads with nothing
-// to synchronise: in one block with the other role each barrier would wait for these loads), even blocks
-//  * publish the first / one-past-last sorted position of every occupied x-row (only occupied rows are ever read),
-//  * cut tiles: <= 64 consecutive sorted points of one x-row spanning <= span+1 cells.  Tiles are cut at every 64th
+// ---- per-row table and tiles ---------------------------------------------------------
+// (The sorted cloud itself is written by the cell sort's last pass, k_sort.hip.)  A block covers kTbSpan sorted positions:
+//  * it publishes the first / one-past-last sorted position of every occupied x-row (only occupied rows are ever read),
+//  * it cuts tiles: <= 64 consecutive sorted points of one x-row spanning <= span+1 cells.  Tiles are cut at every 64th
 //    point counted from the start of the x-row (so dense rows give full tiles: ~90 % lane fill) and a 64-chunk that
 //    spans more than `span` cell steps (sparse rows) is cut again at aligned (span+1)-cell groups, which bounds the
 //    candidate count of a tile: without the bound a sparse row yields tiles 20x the mean that the whole grid waits for.
 // The start of a point's row is the nearest row start at or before it: inside the block a running maximum over the
 // start flags; for the row that is already running when the block begins, the block walks the sorted keys backwards
-// (kTbSpan positions per step) -- no table written by another block is read, so nothing has to precede this launch.
+// (kTbSpan positions per step) -- no table written by another block is read.
 // A thread owns kTbPer CONSECUTIVE positions (one 16 B key load): the block's chain of barrier-separated steps
 // (~10 us of latency) is paid once per 4096 positions and a 1 M-point frame is one round of resident blocks.
+//
+// Filing: every tile goes to the list of its cost class (below), and inside a class the tiles stand in POSITION order --
+// whatever order the blocks run in: the rank of a tile among the block's tiles of its class comes from wave ballots and a
+// per-wave table (thread order = position order), the number of tiles of the class in the blocks before from a chained
+// scan over the blocks (one record per block and class, decoupled look-back as in gm_compact.hpp, a wave per class, 64
+// records per trip; blocks take their span by ticket).  Round 3 filed by atomic arrival (rank from an LDS counter, base
+// from one global atomic per block and class): k_normals deals runs of 128 consecutive list entries to one XCD so that
+// neighbouring tiles share an L2, and with arrival order inside a class those runs were made of pieces from all over the
+// frame: 124.7 -> 178.1 MB of HBM traffic per launch (profiles/r03_normals_pmc.json).  Position order is also the same
+// from run to run.  A class other than the last holds tiles of >= 2 points, i.e. at most n / 2 of them: no list can
+// overflow (Slot::tile_seg).
 #ifndef GM_TBTHREADS
 #define GM_TBTHREADS 1024
 #endif
 constexpr int kTbThreads = GM_TBTHREADS;
 constexpr int kTbPer = 4;
 constexpr int kTbSpan = kTbThreads * kTbPer;
-__global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const float4 *__restrict__ crop4,
-                                                               const uint32_t *__restrict__ perm,
-                                                               const uint32_t *__restrict__ skeys,
+static_assert(kTileClasses <= kTbThreads / kWave, "a wave of the cutter per cost class");
+uint32_t tile_cutter_blocks(uint32_t n_cap) { return (n_cap + kTbSpan - 1) / kTbSpan; }
+__global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const uint32_t *__restrict__ skeys,
                                                                DevCounters *__restrict__ ctr, uint32_t nx, uint32_t span,
-                                                               float4 *__restrict__ spts4,
-                                                               uint2 *__restrict__ row_bounds /* [ny*nz]: begin, end */,
-                                                               uint2 *__restrict__ tiles, uint32_t tiles_cap, uint32_t tile_seg)
+                                                               uint2 *__restrict__ row_bounds /* [ny*nz]: begin, end */, uint32_t nrows,
+                                                               uint2 *__restrict__ tiles, uint32_t tiles_cap, uint32_t tile_seg,
+                                                               ScanState st)
 {
+    constexpr uint64_t kAggregate = 1ull << 32, kInclusive = 2ull << 32;
     __shared__ uint32_t wstart[kTbThreads / kWave];
-    __shared__ uint32_t s_start0;
-    __shared__ uint32_t ccount[kTileClasses], cbase[kTileClasses];
-    if (threadIdx.x < kTileClasses) ccount[threadIdx.x] = 0u;   // (ordered before its use by the barriers below; the gather blocks return before them)
+    __shared__ uint32_t s_start0, s_tile;
+    __shared__ uint32_t wcls[kTbThreads / kWave][kTileClasses];   // per wave: tiles of each class, then the wave's first rank
     const uint32_t n = ctr->n_cropped;
-    const uint32_t base = (blockIdx.x >> 1) * (uint32_t)kTbSpan;
-    if (base >= n) return;  // uniform per block
-    if (blockIdx.x & 1u) {
-        uint32_t idx[kTbPer];
-        float4 p[kTbPer];
-#pragma unroll
-        for (int j = 0; j < kTbPer; ++j) {
-            const uint32_t s = base + j * kTbThreads + threadIdx.x;
-            idx[j] = s < n ? perm[s] : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < kTbPer; ++j) p[j] = crop4[idx[j]];   // (n > 0 here: index 0 is readable)
-#pragma unroll
-        for (int j = 0; j < kTbPer; ++j) {
-            const uint32_t s = base + j * kTbThreads + threadIdx.x;
-            p[j].w = __uint_as_float(idx[j]);  // cropped index rides in the pad lane
-            if (s < n) spts4[s] = p[j];
-        }
-        return;
+    if (n == 0) return;   // (no ticket is taken: the word stays 0)
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(st.ticket, 1u);
+        if (t == gridDim.x - 1) atomicExch(st.ticket, 0u);   // every ticket of this launch has been taken
+        s_tile = t;
     }
+    __syncthreads();
+    const uint32_t blk = s_tile;
+    const uint32_t base = blk * (uint32_t)kTbSpan;
+    if (base >= n) return;  // uniform per block; nothing after the end is ever looked at
+    const uint32_t nblk = (n + (uint32_t)kTbSpan - 1u) / (uint32_t)kTbSpan;
     const int w = threadIdx.x / kWave;
     const uint32_t s0 = base + threadIdx.x * (uint32_t)kTbPer;   // this thread's first position
     // keys of the thread's positions and of the two around them (the buffers hold whole 16 B groups: capacity is
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const float4 *__r
         const uint32_t s = s0 + j;
         row[j] = key[j + 1] / nx;
         starts[j] = false;
-        if (s < n) {
+        if (s < n && row[j] < nrows) {   // (a key is always inside the grid: no stray store, whatever the sort left)
             starts[j] = s == 0 || key[j] / nx != row[j];
             if (starts[j]) { row_bounds[row[j]].x = s; m = s + 1u; }
             if (s + 1 == n || key[j + 2] / nx != row[j]) row_bounds[row[j]].y = s + 1;
@@ -264,29 +264,69 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const float4 *__r
             }
         }
     }
-    // ---- the block files its tiles by class: rank inside the block from an LDS counter per class, ONE global atomic per
-    // block and class for the base.  (The order of the tiles inside a class is not fixed from run to run; nothing depends on
-    // it: a tile's results are its own.)  Classes 0 .. K-2 have tile_seg entries each; what does not fit goes to the last
-    // class, which can hold every tile of the frame.
+    // ---- rank of every tile among the block's tiles of its class, in position order (thread, then item)
     uint32_t rank[kTbPer];
 #pragma unroll
-    for (int j = 0; j < kTbPer; ++j) rank[j] = cnt[j] ? atomicAdd(&ccount[tcls[j]], 1u) : 0u;
+    for (int j = 0; j < kTbPer; ++j) rank[j] = 0;
+    for (int c = 0; c < kTileClasses; ++c) {   // (wave-uniform loop: four ballots per class)
+        uint32_t lt = 0, tot = 0;
+#pragma unroll
+        for (int j = 0; j < kTbPer; ++j) {
+            const uint64_t mk = __ballot(cnt[j] && tcls[j] == (uint32_t)c);
+            lt += (uint32_t)__popcll(mk & lanemask_lt());
+            tot += (uint32_t)__popcll(mk);
+        }
+        uint32_t in_thread = 0;
+#pragma unroll
+        for (int j = 0; j < kTbPer; ++j)
+            if (cnt[j] && tcls[j] == (uint32_t)c) { rank[j] = lt + in_thread; ++in_thread; }
+        if (lane_id() == 0) wcls[w][c] = tot;
+    }
     __syncthreads();
-    if (threadIdx.x < kTileClasses) {
-        const uint32_t c = ccount[threadIdx.x];
-        cbase[threadIdx.x] = c ? atomicAdd(&ctr->n_tiles_c[threadIdx.x][0], c) : 0u;
+    // ---- a wave per class: the waves' counts -> first rank of every wave, the block's count; then the blocks before
+    if (w < kTileClasses) {
+        const int c = w, lane = lane_id();
+        const uint32_t mine = lane < kTbThreads / kWave ? wcls[lane][c] : 0u;
+        const uint32_t inc = wave_inclusive_scan(mine);
+        const uint32_t total = __shfl(inc, kWave - 1, kWave);
+        const uint32_t epoch = scan_epoch(st);
+        const uint64_t tag = (uint64_t)epoch << 34;
+        unsigned long long *rec = st.status + c;   // record of (block b, this class): rec[b * kTileClasses]
+        if (lane == 0)
+            __hip_atomic_store(&rec[(size_t)blk * kTileClasses], tag | (blk == 0 ? kInclusive : kAggregate) | total, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t prev = 0;
+        if (blk > 0) {
+            int32_t top = (int32_t)blk - 1;
+            for (;;) {
+                const int32_t idx = top - lane;
+                // (blocks "before block 0" read as an inclusive prefix of 0: the walk always ends there at the latest)
+                const uint64_t sv = idx >= 0 ? __hip_atomic_load(&rec[(size_t)idx * kTileClasses], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                             : (tag | kInclusive);
+                const bool ready = (sv >> 34) == (uint64_t)epoch && ((sv >> 32) & 3u) != 0u;
+                const bool incl = ready && ((sv >> 32) & 3u) == 2u;
+                const uint64_t im = __ballot(incl), rm = __ballot(ready);
+                const int first = im ? (int)__builtin_ctzll(im) : kWave;   // lanes up to and including the first inclusive record
+                const uint64_t need = first >= kWave - 1 ? ~0ull : ((2ull << first) - 1ull);
+                if ((rm & need) != need) { __builtin_amdgcn_s_sleep(1); continue; }
+                prev += wave_sum(lane <= first ? (uint32_t)sv : 0u);
+                if (im) break;
+                top -= kWave;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&rec[(size_t)blk * kTileClasses], tag | kInclusive | (uint64_t)(prev + total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane < kTbThreads / kWave) wcls[lane][c] = prev + inc - mine;   // first list index of wave `lane` in class c
+        if (lane == 0 && blk == nblk - 1) ctr->n_tiles_c[c][0] = prev + total;   // the last block knows the class's length
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < kTbPer; ++j) {
         if (cnt[j]) {
             const uint2 t = make_uint2(s0 + j, tend[j] - (s0 + j));  // first query, number of queries
-            uint32_t c = tcls[j], idx = cbase[c] + rank[j];
-            if (c + 1u < (uint32_t)kTileClasses && idx >= tile_seg) {   // class segment full
-                c = (uint32_t)kTileClasses - 1u;
-                idx = atomicAdd(&ctr->n_tiles_c[c][0], 1u);
-            }
-            if (c + 1u < (uint32_t)kTileClasses || idx < tiles_cap) tiles[(size_t)c * tile_seg + idx] = t;
+            const uint32_t c = tcls[j], idx = wcls[w][c] + rank[j];
+            if (idx < (c + 1u < (uint32_t)kTileClasses ? tile_seg : tiles_cap)) tiles[(size_t)c * tile_seg + idx] = t;   // (always: see Slot::tile_seg)
         }
     }
 }
@@ -1688,6 +1728,15 @@ __global__ __launch_bounds__(kNrThreads) void k_normals_valu(NormalsArgs A)
     for (uint32_t t = wave_id; t < ntiles; t += n_waves) normals_tile_valu(A, lds[threadIdx.x / kWave], tile_at(A, L, t));
 }
 
+// bits needed by the largest cell key
+int cell_key_bits(const GridParams &g)
+{
+    const uint64_t ncell = (uint64_t)g.nx * g.ny * g.nz;
+    int bits = 1;
+    while ((1ull << bits) < ncell) ++bits;
+    return bits;
+}
+
 uint32_t max_tiles(uint32_t n_cap, const GridParams &g)
 {
     // every aligned cell group adds at most one partially filled tile, every 64-chunk at most one more
@@ -1701,22 +1750,21 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
                              bool scratch_cleared, hipStream_t s)
 {
     if (n_cap == 0) return;
-    // bits needed by the largest cell key
-    const uint64_t ncell = (uint64_t)g.nx * g.ny * g.nz;
-    int bits = 1;
-    while ((1ull << bits) < ncell) ++bits;
-    // (moving the cropped rows into sorted order inside the sort's last pass, which knows every item's final place, was
-    // measured: its scattered 16-byte row writes cost the pass 13 us, the gather blocks of k_rows_and_tiles below cost 8)
-    const int where = launch_radix_sort(sl.keys_a, sl.vals_a, sl.keys_b, sl.vals_b, &sl.ctr->n_cropped, n_cap, bits,
-                                        sl.sort, scratch_cleared, s);
+    // cell sort; its last pass writes the sorted cloud (spts4) itself.  scratch_cleared: the crop has counted the digit totals.
+    const int where = launch_radix_sort(sl.keys_a, sl.vals_a, sl.keys_b, sl.vals_b, &sl.ctr->n_cropped, n_cap, cell_key_bits(g),
+                                        sl, scratch_cleared, s, sl.crop4, sl.spts4);
     uint32_t *skeys = where ? sl.keys_b : sl.keys_a;
-    uint32_t *perm = where ? sl.vals_b : sl.vals_a;
     sl.skeys = skeys;
     // rows the frame leaves unoccupied must read as empty ranges in k_normals' window searches
     if (!scratch_cleared) hipMemsetAsync(sl.row_bounds, 0, sizeof(uint2) * (size_t)g.ny * (size_t)g.nz, s);
-    hipLaunchKernelGGL(k_rows_and_tiles, dim3(2u * ((n_cap + kTbSpan - 1) / kTbSpan)), dim3(kTbThreads), 0, s,
-                       (const float4 *)sl.crop4, (const uint32_t *)perm, (const uint32_t *)skeys, sl.ctr, (uint32_t)g.nx,
-                       (uint32_t)(kTileSpan * (g.xreach - 1)), sl.spts4, sl.row_bounds, sl.tiles, sl.tiles_cap, sl.tile_seg);
+    {
+        ScanState st = next_scan(sl);
+        st.status = sl.tile_rec;
+        st.ticket = sl.sort.ticket + 1;
+        hipLaunchKernelGGL(k_rows_and_tiles, dim3(tile_cutter_blocks(n_cap)), dim3(kTbThreads), 0, s, (const uint32_t *)skeys, sl.ctr,
+                           (uint32_t)g.nx, (uint32_t)(kTileSpan * (g.xreach - 1)), sl.row_bounds, (uint32_t)g.ny * (uint32_t)g.nz, sl.tiles,
+                           sl.tiles_cap, sl.tile_seg, st);
+    }
     // one wave per tile: four tiles per block
     // A wave per tile for twice the tiles of a dense frame (n / 64: full 64-point tiles); a frame with more -- sparse rows
     // cut into many short tiles, at most max_tiles() -- has the rest walked by the kernel's second, looped copy of the

@@ -67,7 +67,7 @@ struct HeadPred {
     __device__ __forceinline__ bool operator()(uint32_t s, Payload &) const { return s == 0 || skeys[s] != skeys[s - 1]; }
 };
 struct HeadEmit {
-    static constexpr bool kHasFinish = false;
+    static constexpr bool kHasFinish = false, kHasPrepare = false;
     uint32_t *__restrict__ seg_start;
     __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst, const NoPayload &) const { seg_start[dst] = src; }
 };
@@ -103,7 +103,7 @@ struct DensePred {
     __device__ __forceinline__ bool operator()(uint32_t i, Payload &) const { return table[i].cnt != 0; }
 };
 struct DenseEmit {
-    static constexpr bool kHasFinish = false;
+    static constexpr bool kHasFinish = false, kHasPrepare = false;
     const VoxCell *__restrict__ table;
     float4 *__restrict__ vox4;
     double lo, inv_scale;
@@ -134,7 +134,7 @@ void launch_voxel_grid(Slot &sl, uint32_t n_cap, float leaf, int key_bits, hipSt
     hipLaunchKernelGGL(k_voxel_keys, dim3(gb), dim3(256), 0, s, (const float4 *)sl.valid4, (const DevCounters *)sl.ctr,
                        (const VoxelParams *)sl.voxp, sl.keys_a);
     const int where = launch_radix_sort(sl.keys_a, sl.vals_a, sl.keys_b, sl.vals_b, &sl.ctr->vox_n, n_cap, key_bits,
-                                        sl.sort, false, s);
+                                        sl, false, s);
     const uint32_t *skeys = where ? sl.keys_b : sl.keys_a;
     const uint32_t *perm = where ? sl.vals_b : sl.vals_a;
     HeadPred pred{skeys};

@@ -457,17 +457,11 @@ def test_normals_grid_stride_path_is_bitwise_identical(gm):
         assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
 
 
-@pytest.mark.parametrize("seg", [None, "3"])
-def test_tile_list_class_overflow_keeps_every_tile(gm, oc, seg, monkeypatch):
-    """k_normals walks its tiles by cost class (x extent); every class but the last has room for capacity / 8 tiles and a
-    full one overflows into the last (k_rows_and_tiles, csrc/k_normals.hip).  A lattice cloud whose rows hold one point
-    every 1.2 r is cut into tiles of two or three points with two extents only: far more tiles per class than a segment
-    holds (and with GM_TEST_TILE_SEG=3, read when a context sizes its buffers, every class of any frame overflows).
-    Every point must still get its neighbours (counts bit-exact) and its normal."""
-    if seg:
-        monkeypatch.setenv("GM_TEST_TILE_SEG", seg)
-    else:
-        monkeypatch.delenv("GM_TEST_TILE_SEG", raising=False)
+def test_tile_lists_hold_every_tile_of_a_sparse_lattice(gm, oc):
+    """k_normals walks its tiles by cost class (x extent).  A class other than the last holds tiles of at least two points,
+    so no list can hold more than capacity / 2 tiles and none can overflow (k_rows_and_tiles, csrc/k_normals.hip).  A
+    lattice cloud whose rows hold one point every 1.2 r is cut into tiles of two or three points with two extents only --
+    as many tiles per class as a frame can have.  Every point must get its neighbours (counts bit-exact) and its normal."""
     from geometric_mapping_amd import _lib
     r = 0.25
     ax = np.arange(-4.8, 4.8, 1.2 * r, dtype=np.float32)
@@ -494,7 +488,7 @@ def test_tile_list_class_overflow_keeps_every_tile(gm, oc, seg, monkeypatch):
 
 def test_chained_scan_epochs_wrap_cleanly(gm):
     """The chained scans tag their records with an epoch that wraps (host counter: every 2^29 - 2 launches of a slot;
-    replayed graphs: every 2^26 frames).  At the wrap the record array is cleared so that no record of the previous
+    replayed graphs: every 2^24 frames).  At the wrap the record array is cleared so that no record of the previous
     period can read as ready.  The counters are started just below the wrap (GM_TEST_*, read at context creation -> child
     processes): frames of changing size on either side of it must be the frames of an ordinary context, bit for bit."""
     import subprocess, sys, tempfile, os
@@ -518,8 +512,8 @@ def test_chained_scan_epochs_wrap_cleanly(gm):
         runs = {}
         for tag, flags, extra in (("plain", 0, {}), ("host_wrap", 0, {"GM_TEST_SCAN_EPOCH": str(0x1FFFFFFE - 7)}),
                                   ("graph", _lib.GM_CFG_GRAPH, {}),
-                                  ("graph_wrap", _lib.GM_CFG_GRAPH, {"GM_TEST_FRAME_COUNTER": str(0x2000000 - 3)}),
-                                  ("graph_wrap2", _lib.GM_CFG_GRAPH, {"GM_TEST_FRAME_COUNTER": str(0x4000000 - 3)})):
+                                  ("graph_wrap", _lib.GM_CFG_GRAPH, {"GM_TEST_FRAME_COUNTER": str(0x800000 - 3)}),
+                                  ("graph_wrap2", _lib.GM_CFG_GRAPH, {"GM_TEST_FRAME_COUNTER": str(0x1000000 - 3)})):
             env = dict(os.environ)
             env.pop("GM_TEST_SCAN_EPOCH", None); env.pop("GM_TEST_FRAME_COUNTER", None)
             env.update(extra)
