@@ -127,8 +127,24 @@ constexpr int kTbPer = 4;
 constexpr int kTbSpan = kTbThreads * kTbPer;
 static_assert(kTileClasses <= kTbThreads / kWave, "a wave of the cutter per cost class");
 uint32_t tile_cutter_blocks(uint32_t n_cap) { return (n_cap + kTbSpan - 1) / kTbSpan; }
+#ifdef GM_SORT_TIMELINE   // diagnostic builds (tools/sort_timeline.py): 100 MHz ticks of every cutter block's phases
+__device__ unsigned long long gm_cut_tl[512][8];
+#define GM_CT_STAMP(k) do { if (threadIdx.x == 0 && blk < 512u) gm_cut_tl[blk][k] = wall_clock64(); } while (0)
+#else
+#define GM_CT_STAMP(k) do {} while (0)
+#endif
+// x / d for a launch-invariant divisor: inv_d = a double just below 1 / d, so the truncated product is the quotient or one
+// less (x < 2^32: the product's rounding error is far below 1 / d); ~1/4 of the instructions of the integer division
+__device__ __forceinline__ uint32_t div_inv(uint32_t x, uint32_t d, double inv_d)
+{
+    uint32_t q = (uint32_t)((double)x * inv_d);
+    if (x - q * d >= d) ++q;
+    return q;
+}
+
 __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const uint32_t *__restrict__ skeys,
                                                                DevCounters *__restrict__ ctr, uint32_t nx, uint32_t span,
+                                                               double inv_nx, double inv_group,
                                                                uint2 *__restrict__ row_bounds /* [ny*nz]: begin, end */, uint32_t nrows,
                                                                uint2 *__restrict__ tiles, uint32_t tiles_cap, uint32_t tile_seg,
                                                                ScanState st)
@@ -136,7 +152,16 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const uint32_t *_
     constexpr uint64_t kAggregate = 1ull << 32, kInclusive = 2ull << 32;
     __shared__ uint32_t wstart[kTbThreads / kWave];
     __shared__ uint32_t s_start0, s_tile;
+    // the block's keys and the kTileQ keys on either side of them: every key a tile cut of this block looks at (the start
+    // of a tile's 64-chunk lies < 64 positions before the tile, its end < 64 behind) -- the binary searches below run on
+    // LDS.  (On the sorted array in memory they were chains of dependent L2 round trips, two searches of six steps for a
+    // tile of a sparse row: the blocks with such rows finished 6 us after the others, and every block behind them in the
+    // chained scan waited for their counts.)
+    __shared__ uint32_t lk[kTbSpan + 2 * kTileQ];
     __shared__ uint32_t wcls[kTbThreads / kWave][kTileClasses];   // per wave: tiles of each class, then the wave's first rank
+#ifdef GM_SORT_TIMELINE
+    const unsigned long long tl_entry = wall_clock64();
+#endif
     const uint32_t n = ctr->n_cropped;
     if (n == 0) return;   // (no ticket is taken: the word stays 0)
     if (threadIdx.x == 0) {
@@ -148,6 +173,10 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const uint32_t *_
     const uint32_t blk = s_tile;
     const uint32_t base = blk * (uint32_t)kTbSpan;
     if (base >= n) return;  // uniform per block; nothing after the end is ever looked at
+#ifdef GM_SORT_TIMELINE
+    if (threadIdx.x == 0 && blk < 512u) gm_cut_tl[blk][0] = tl_entry;
+#endif
+    GM_CT_STAMP(1);   // ticket in hand
     const uint32_t nblk = (n + (uint32_t)kTbSpan - 1u) / (uint32_t)kTbSpan;
     const int w = threadIdx.x / kWave;
     const uint32_t s0 = base + threadIdx.x * (uint32_t)kTbPer;   // this thread's first position
@@ -155,30 +184,47 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const uint32_t *_
     // allocated in multiples of 4 and the first position of a thread is a multiple of 4)
     uint32_t key[kTbPer + 2];
     {
+        // (positions at or past n hold whatever the buffer holds: every use below is guarded by a position < n)
         const uint4 k4 = s0 < n ? *reinterpret_cast<const uint4 *>(skeys + s0) : make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4 *>(&lk[kTileQ + threadIdx.x * kTbPer]) = k4;
+        if (threadIdx.x < 2 * kTileQ / kTbPer) {   // the halos: 16 threads each
+            const bool left = threadIdx.x < kTileQ / kTbPer;
+            const uint32_t h = left ? threadIdx.x : threadIdx.x - kTileQ / kTbPer;
+            const uint32_t pos = left ? base - (uint32_t)kTileQ + h * kTbPer : base + (uint32_t)kTbSpan + h * kTbPer;
+            const bool ok = left ? base >= (uint32_t)kTileQ : pos < n;   // (base is a multiple of kTbSpan: all of the left halo or none)
+            const uint4 h4 = ok ? *reinterpret_cast<const uint4 *>(skeys + pos) : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4 *>(&lk[left ? h * kTbPer : kTileQ + kTbSpan + h * kTbPer]) = h4;
+        }
+        __syncthreads();
         key[1] = k4.x; key[2] = k4.y; key[3] = k4.z; key[4] = k4.w;
-        key[0] = (s0 > 0 && s0 < n) ? skeys[s0 - 1] : 0u;
-        key[kTbPer + 1] = s0 + kTbPer < n ? skeys[s0 + kTbPer] : 0u;
+        key[0] = (s0 > 0 && s0 < n) ? lk[kTileQ + threadIdx.x * kTbPer - 1] : 0u;
+        key[kTbPer + 1] = s0 + kTbPer < n ? lk[kTileQ + threadIdx.x * kTbPer + kTbPer] : 0u;
     }
-    uint32_t row[kTbPer];
+    const uint32_t *const lkeys = lk + kTileQ - base;   // lkeys[position] for positions in [base - 64, base + span + 64)
+    // (The keys ascend.  Whether two of them lie in the same x-row, or in the same cell group of a row, is a comparison with
+    // the row's / group's first key -- the cutter used to divide for each such question, inside the binary searches too, and
+    // was bound by those instructions: the blocks of sparse rows, with many short tiles, published 6 us after the others.)
+    uint32_t row[kTbPer], rbeg[kTbPer];   // x-row of the position, first key of that row
     bool starts[kTbPer];
     uint32_t m = 0;  // nearest row start at or before the thread's last position, +1; 0 = none in this thread
 #pragma unroll
     for (int j = 0; j < kTbPer; ++j) {
         const uint32_t s = s0 + j;
-        row[j] = key[j + 1] / nx;
+        if (j == 0 || key[j + 1] >= rbeg[j - 1] + nx) { row[j] = div_inv(key[j + 1], nx, inv_nx); rbeg[j] = row[j] * nx; }
+        else { row[j] = row[j - 1]; rbeg[j] = rbeg[j - 1]; }
         starts[j] = false;
         if (s < n && row[j] < nrows) {   // (a key is always inside the grid: no stray store, whatever the sort left)
-            starts[j] = s == 0 || key[j] / nx != row[j];
+            starts[j] = s == 0 || key[j] < rbeg[j];
             if (starts[j]) { row_bounds[row[j]].x = s; m = s + 1u; }
-            if (s + 1 == n || key[j + 2] / nx != row[j]) row_bounds[row[j]].y = s + 1;
+            if (s + 1 == n || key[j + 2] >= rbeg[j] + nx) row_bounds[row[j]].y = s + 1;
         }
     }
+    GM_CT_STAMP(2);   // keys loaded, row table written
     // ---- start of the row that runs into this block
     if (threadIdx.x == 0) s_start0 = starts[0] ? base : 0xFFFFFFFFu;
     __syncthreads();
     {
-        const uint32_t row0 = skeys[base] / nx;
+        const uint32_t rbeg0 = div_inv(lkeys[base], nx, inv_nx) * nx;   // first key of the row that runs into the block
         for (uint32_t back = 0; s_start0 == 0xFFFFFFFFu; back += (uint32_t)kTbSpan) {  // block-uniform
             // positions base-back-4(tid+1) .. +3: the row start is the one position of row0 whose predecessor is not
             const uint32_t off = back + (threadIdx.x + 1u) * (uint32_t)kTbPer;
@@ -188,14 +234,15 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const uint32_t *_
                 const uint4 k4 = *reinterpret_cast<const uint4 *>(skeys + t0);
                 const uint32_t kk[5] = {t0 ? skeys[t0 - 1] : 0u, k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
-                for (int j = 0; j < kTbPer; ++j)
-                    if (kk[j + 1] / nx == row0 && (t0 + j == 0 || kk[j] / nx != row0)) hit = t0 + j;
+                for (int j = 0; j < kTbPer; ++j)   // (every key before `base` is <= the block's first: inside the row iff >= its first key)
+                    if (kk[j + 1] >= rbeg0 && (t0 + j == 0 || kk[j] < rbeg0)) hit = t0 + j;
             }
             __syncthreads();            // everyone has read s_start0 for the loop test
             if (hit != 0xFFFFFFFFu) s_start0 = hit;   // at most one thread over the whole walk
             __syncthreads();
         }
     }
+    GM_CT_STAMP(3);   // start of the row running into the block known
     // ---- exclusive running maximum of m over the threads before this one
     uint32_t mi = m;
 #pragma unroll
@@ -221,25 +268,25 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const uint32_t *_
         cnt[j] = 0; tend[j] = 0; tcls[j] = 0;
         if (s < n) {
             if (starts[j]) row_start = s;
-            const uint32_t r = row[j], kj = key[j + 1];
+            const uint32_t kj = key[j + 1], rb = rbeg[j], rend = rb + nx;   // the row's keys: [rb, rend)
             const uint32_t cstart = row_start + ((s - row_start) / (uint32_t)kTileQ) * (uint32_t)kTileQ;
-            const uint32_t my_group = (kj - r * nx) / group;
             // a tile can only start at the chunk start or where the cell group changes: everything else is skipped
             // before any further load
             const bool at_cstart = s == cstart;
-            const bool group_edge = !at_cstart && my_group != (key[j] - r * nx) / group;
+            const uint32_t gbeg = rb + div_inv(kj - rb, group, inv_group) * group;   // first key of the point's cell group
+            const bool group_edge = !at_cstart && key[j] < gbeg;
             if (at_cstart || group_edge) {
                 // the chunk ends 64 points on or with the row (keys ascend: a short binary search in the row's last chunk)
                 uint32_t cend = cstart + kTileQ;
-                if (cend > n || skeys[cend - 1] / nx != r) {
+                if (cend > n || lkeys[cend - 1] >= rend) {
                     uint32_t lo = s + 1, hi = cend < n ? cend : n;
                     while (lo < hi) {
                         const uint32_t mid = (lo + hi) >> 1;
-                        if (skeys[mid] / nx == r) lo = mid + 1; else hi = mid;
+                        if (lkeys[mid] < rend) lo = mid + 1; else hi = mid;
                     }
                     cend = lo;
                 }
-                const uint32_t chunk_ext = skeys[cend - 1] - skeys[cstart];  // same row: key difference = cell steps
+                const uint32_t chunk_ext = lkeys[cend - 1] - lkeys[cstart];  // same row: key difference = cell steps
                 const bool sparse = chunk_ext > span;
                 if (at_cstart || sparse) {
                     cnt[j] = 1;
@@ -247,23 +294,25 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const uint32_t *_
                     tend[j] = cend;
                     uint32_t ext = chunk_ext;
                     if (sparse) {
+                        const uint32_t gend = gbeg + group;
                         uint32_t lo = s + 1, hi = cend;
                         while (lo < hi) {
                             const uint32_t mid = (lo + hi) >> 1;
-                            if ((skeys[mid] - r * nx) / group == my_group) lo = mid + 1; else hi = mid;
+                            if (lkeys[mid] < gend) lo = mid + 1; else hi = mid;
                         }
                         tend[j] = lo;
-                        ext = skeys[lo - 1] - kj;
+                        ext = lkeys[lo - 1] - kj;
                     }
                     // cost class: a tile's candidates are those of windows 2 r + its own x extent long in every row around
                     // it -- their number follows the extent (correlation 0.99 on the 1 M-point frame), so the extent orders
                     // the tiles by cost: class 0 = longest
-                    const uint32_t c8 = ext * (uint32_t)kTileClasses / group;
+                    const uint32_t c8 = div_inv(ext * (uint32_t)kTileClasses, group, inv_group);
                     tcls[j] = (uint32_t)(kTileClasses - 1) - (c8 < (uint32_t)kTileClasses - 1u ? c8 : (uint32_t)kTileClasses - 1u);
                 }
             }
         }
     }
+    GM_CT_STAMP(4);   // tiles cut and classified (thread 0's; the barrier below waits for everybody's)
     // ---- rank of every tile among the block's tiles of its class, in position order (thread, then item)
     uint32_t rank[kTbPer];
 #pragma unroll
@@ -283,6 +332,7 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const uint32_t *_
         if (lane_id() == 0) wcls[w][c] = tot;
     }
     __syncthreads();
+    GM_CT_STAMP(5);   // ranked inside the block
     // ---- a wave per class: the waves' counts -> first rank of every wave, the block's count; then the blocks before
     if (w < kTileClasses) {
         const int c = w, lane = lane_id();
@@ -321,6 +371,7 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const uint32_t *_
         if (lane == 0 && blk == nblk - 1) ctr->n_tiles_c[c][0] = prev + total;   // the last block knows the class's length
     }
     __syncthreads();
+    GM_CT_STAMP(6);   // looked back
 #pragma unroll
     for (int j = 0; j < kTbPer; ++j) {
         if (cnt[j]) {
@@ -329,6 +380,10 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const uint32_t *_
             if (idx < (c + 1u < (uint32_t)kTileClasses ? tile_seg : tiles_cap)) tiles[(size_t)c * tile_seg + idx] = t;   // (always: see Slot::tile_seg)
         }
     }
+#ifdef GM_SORT_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GM_CT_STAMP(7);   // stores acknowledged
+#endif
 }
 
 // fp64 reciprocal / reciprocal square root from the hardware estimate (v_rcp_f64 / v_rsq_f64) and one Newton step:
@@ -1737,6 +1792,9 @@ int cell_key_bits(const GridParams &g)
     return bits;
 }
 
+// a double just below 1 / d (k_rows_and_tiles' div_inv)
+static double inv_below(uint32_t d) { return nextafter(1.0 / (double)(d ? d : 1u), 0.0); }
+
 uint32_t max_tiles(uint32_t n_cap, const GridParams &g)
 {
     // every aligned cell group adds at most one partially filled tile, every 64-chunk at most one more
@@ -1762,7 +1820,8 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
         st.status = sl.tile_rec;
         st.ticket = sl.sort.ticket + 1;
         hipLaunchKernelGGL(k_rows_and_tiles, dim3(tile_cutter_blocks(n_cap)), dim3(kTbThreads), 0, s, (const uint32_t *)skeys, sl.ctr,
-                           (uint32_t)g.nx, (uint32_t)(kTileSpan * (g.xreach - 1)), sl.row_bounds, (uint32_t)g.ny * (uint32_t)g.nz, sl.tiles,
+                           (uint32_t)g.nx, (uint32_t)(kTileSpan * (g.xreach - 1)), inv_below((uint32_t)g.nx),
+                           inv_below((uint32_t)(kTileSpan * (g.xreach - 1)) + 1u), sl.row_bounds, (uint32_t)g.ny * (uint32_t)g.nz, sl.tiles,
                            sl.tiles_cap, sl.tile_seg, st);
     }
     // one wave per tile: four tiles per block
@@ -1848,5 +1907,14 @@ extern "C" int gm_debug_phases(unsigned long long *out16)
     unsigned long long z[16] = {};
     if (rc == 0) rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(gm::gm_phase_ticks), z, sizeof(z));
     return rc;
+}
+#endif
+
+#ifdef GM_SORT_TIMELINE
+// diagnostic builds only: [block][8] ticks (100 MHz) of the last tile cutter launch
+extern "C" int gm_debug_cutter_timeline(unsigned long long *out)
+{
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gm::gm_cut_tl), sizeof(unsigned long long) * 512 * 8);
 }
 #endif

@@ -48,4 +48,28 @@ for p in range(4):
     out["pass%d" % p]["lookback_after_inputs_us"] = {"median": round(float(np.median(lb_end - np.maximum(need, lb_start))), 2), "max": round(float((lb_end - np.maximum(need, lb_start)).max()), 2)}
     out["pass%d" % p]["entry_at_us"] = {"median": round(float(np.median(tp[:, 0] - t0) / 100.0), 2), "max": round(float((tp[:, 0] - t0).max() / 100.0), 2)}
     out["pass%d" % p]["end_at_us"] = {"median": round(float(np.median(tp[:, 7] - t0) / 100.0), 2), "max": round(float((tp[:, 7] - t0).max() / 100.0), 2)}
+# the tile cutter (k_rows_and_tiles) of the same frame
+lib.gm_debug_cutter_timeline.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+cbuf = (ctypes.c_uint64 * (512 * 8))()
+if lib.gm_debug_cutter_timeline(cbuf) == 0:
+    ct = np.frombuffer(cbuf, dtype=np.uint64).reshape(512, 8).astype(np.int64)
+    ok = (ct[:, 0] > 0) & (ct[:, 7] >= ct[:, 0])
+    ct = ct[ok]
+    if len(ct):
+        cn = ["ticket", "keys+rows", "row_walk", "cut+classify", "rank", "lookback", "write"]
+        d = np.diff(ct, axis=1) / 100.0
+        out["cutter"] = {"blocks": int(len(ct)), "span_us": float((ct[:, 7].max() - ct[:, 0].min()) / 100.0),
+                         "median_us": {n: round(float(np.median(d[:, i])), 2) for i, n in enumerate(cn)},
+                         "max_us": {n: round(float(d[:, i].max()), 2) for i, n in enumerate(cn)}}
+        t0 = ct[:, 0].min()
+        pub = (ct[:, 5] - t0) / 100.0
+        need = np.maximum.accumulate(pub)
+        lbe = (ct[:, 6] - t0) / 100.0
+        out["cutter"]["publish_at_us"] = {"min": round(float(pub.min()), 2), "median": round(float(np.median(pub)), 2), "p90": round(float(np.quantile(pub, 0.9)), 2), "max": round(float(pub.max()), 2)}
+        out["cutter"]["lookback_after_inputs_us"] = {"median": round(float(np.median(lbe - need)), 2), "max": round(float((lbe - need).max()), 2)}
+        late = np.argsort(-pub)[:6]
+        out["cutter"]["latest_publishers"] = [{"block": int(b), "publish_at": round(float(pub[b]), 2), **{n: round(float(d[b, i]), 2) for i, n in enumerate(cn[:5])}} for b in late]
+        early = np.argsort(pub)[:3]
+        out["cutter"]["earliest_publishers"] = [{"block": int(b), "publish_at": round(float(pub[b]), 2), **{n: round(float(d[b, i]), 2) for i, n in enumerate(cn[:5])}} for b in early]
+        out["cutter"]["entry_at_us"] = {"median": round(float(np.median(ct[:, 0] - t0) / 100.0), 2), "max": round(float((ct[:, 0] - t0).max() / 100.0), 2)}
 print(json.dumps(out, indent=1))
