@@ -141,6 +141,8 @@ def load():
         "gm_process_frame": (C.c_int, [vp, cloudp, resp]),
         "gm_submit_frame": (C.c_int, [vp, u32, cloudp]),
         "gm_wait_frame": (C.c_int, [vp, u32, resp]),
+        "gm_poll_frame": (C.c_int, [vp, u32]),
+        "gm_set_cloud_output": (C.c_int, [vp, u32, fp, u32]),
         "gm_get_cropped_xyz": (C.c_int, [vp, u32, fp, u32, u32p]),
         "gm_get_normals": (C.c_int, [vp, u32, fp, u32, u32p]),
         "gm_get_voxel_centroids": (C.c_int, [vp, u32, fp, u32, u32p]),
@@ -177,6 +179,7 @@ def load():
         "gm_group_get_edges": (C.c_int, [vp, dp, u32, u32p]),
         "gm_group_submit_frame": (C.c_int, [vp, cloudp]),
         "gm_group_wait_frame": (C.c_int, [vp, resp, u32p, u32p]),
+        "gm_group_poll_frame": (C.c_int, [vp]),
         "gm_group_in_flight": (u32, [vp]),
     }
     for name, (res, args) in proto.items():

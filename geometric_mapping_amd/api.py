@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (GM_CFG_DEFAULT, GM_CFG_KEEP_COUNTS, GM_CFG_STAGE_TIMING, GM_CFG_VOXEL_GRID, GM_CLOUD_BIGENDIAN,
-                   GM_CLOUD_DEVICE, GM_CLOUD_PINNED, GM_ERR_CAPACITY, GM_OK, Cloud, Config, FrameResult, GmError, STAGE_NAMES)
+                   GM_CLOUD_DEVICE, GM_CLOUD_PINNED, GM_ERR_CAPACITY, GM_ERR_NOT_READY, GM_OK, Cloud, Config, FrameResult, GmError, STAGE_NAMES)
 
 __all__ = ["GeometricMapping", "GeometricMappingGroup", "GmError", "solve_local_frame", "decode_compressed_map"]
 
@@ -60,6 +60,9 @@ class GeometricMapping:
     # ---- lifetime ----
     def close(self):
         if getattr(self, "_ctx", None):
+            for slot in getattr(self, "_cloud_slots", []):   # (waits for a frame that still writes the buffer)
+                self._L.gm_set_cloud_output(self._ctx, slot, None, 0)
+            self._cloud_slots = []
             for p in getattr(self, "_pinned", []):
                 self._L.gm_host_free(self._ctx, p)
             self._pinned = []
@@ -156,6 +159,26 @@ class GeometricMapping:
         res = FrameResult()
         self._check(self._L.gm_wait_frame(self._ctx, slot, C.byref(res)))
         return self._result(res)
+
+    def poll_frame(self, slot):
+        """True when the slot's submitted frame has finished (wait_frame returns at once); never blocks."""
+        st = self._L.gm_poll_frame(self._ctx, slot)
+        if st == GM_OK:
+            return True
+        if st == GM_ERR_NOT_READY:
+            return False
+        self._check(st)
+
+    def cloud_output(self, slot, capacity):
+        """Registers a page-locked /choppedCloud buffer for the slot (gm_set_cloud_output): every later frame of the slot
+        copies its valid cloud there while the rest of the frame runs.  Returns the float32 [capacity, 4] view
+        (x, y, z, bits(input row)); rows [0, n_valid) are the frame's once wait_frame has returned."""
+        ptr = C.c_void_p()
+        self._check(self._L.gm_host_alloc(self._ctx, int(capacity) * 16, C.byref(ptr)))
+        self._pinned.append(ptr)
+        self._check(self._L.gm_set_cloud_output(self._ctx, slot, C.cast(ptr, C.POINTER(C.c_float)), int(capacity)))
+        self._cloud_slots = getattr(self, "_cloud_slots", []) + [slot]
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(max(int(capacity), 1), 4))[:int(capacity)]
 
     def _fetch(self, fn, slot, width, dtype=np.float32):
         n = C.c_uint32(0)
@@ -468,6 +491,15 @@ class GeometricMappingGroup:
 
     def in_flight(self):
         return int(self._L.gm_group_in_flight(self._grp))
+
+    def poll_frame(self):
+        """True when the oldest frame in flight has finished (wait_frame returns at once); never blocks."""
+        st = self._L.gm_group_poll_frame(self._grp)
+        if st == GM_OK:
+            return True
+        if st == GM_ERR_NOT_READY:
+            return False
+        self._check(st)
 
     def rank_fetch(self, rank, slot, what):
         """Bulky output of a streamed frame: what in {"cropped_xyz", "normals", "voxel_centroids"} -> float32 [n,4]."""

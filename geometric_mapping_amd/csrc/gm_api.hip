@@ -45,11 +45,11 @@ void free_slot_buffers(Slot &sl)
     hipFree(sl.vals_b); hipFree(sl.spts4); hipFree(sl.normals4); hipFree(sl.counts); hipFree(sl.valid4);
     hipFree(sl.vnorm4); hipFree(sl.tiles); hipFree(sl.row_bounds); hipFree(sl.blk); hipFree(sl.tile_partials); hipFree(sl.sort.totals); hipFree(sl.sort.rec);
     hipFree(sl.sort.ticket); hipFree(sl.tile_rec); hipFree(sl.seg_start);
-    hipFree(sl.vox4); hipFree(sl.vox_nn); hipFree(sl.labels);
+    hipFree(sl.vox4); hipFree(sl.vox_nn); hipFree(sl.labels); hipFree(sl.inl_mask);
     if (sl.h_raw) hipHostFree(sl.h_raw);
     sl.d_raw = nullptr; sl.h_raw = nullptr; sl.crop4 = nullptr; sl.keys_a = sl.keys_b = sl.vals_a = sl.vals_b = nullptr;
     sl.spts4 = sl.normals4 = sl.valid4 = sl.vnorm4 = sl.vox4 = nullptr; sl.counts = nullptr; sl.tiles = nullptr; sl.row_bounds = nullptr;
-    sl.blk = nullptr; sl.tile_partials = nullptr; sl.sort = SortScratch{}; sl.tile_rec = nullptr; sl.tile_rec_words = 0; sl.seg_start = nullptr; sl.vox_nn = nullptr; sl.labels = nullptr;
+    sl.blk = nullptr; sl.tile_partials = nullptr; sl.sort = SortScratch{}; sl.tile_rec = nullptr; sl.tile_rec_words = 0; sl.seg_start = nullptr; sl.vox_nn = nullptr; sl.labels = nullptr; sl.inl_mask = nullptr;
     sl.cap = 0; sl.raw_cap = 0; sl.tiles_cap = 0; sl.tile_seg = 0;
 }
 
@@ -214,7 +214,7 @@ gm_status ensure_capacity(gm_ctx *ctx, Slot &sl, uint32_t n, size_t raw_bytes, b
     GM_HIP(ctx, dmalloc(sl.counts, cap));
     GM_HIP(ctx, dmalloc(sl.valid4, cap)); GM_HIP(ctx, dmalloc(sl.vnorm4, cap));
     GM_HIP(ctx, dmalloc(sl.seg_start, cap)); GM_HIP(ctx, dmalloc(sl.vox4, cap));
-    GM_HIP(ctx, dmalloc(sl.vox_nn, cap)); GM_HIP(ctx, dmalloc(sl.labels, cap));
+    GM_HIP(ctx, dmalloc(sl.vox_nn, cap)); GM_HIP(ctx, dmalloc(sl.labels, cap)); GM_HIP(ctx, dmalloc(sl.inl_mask, cap));
     // tile list: kTileListClasses - 1 segments for the tiles with an x extent (>= 2 points each: none of them can hold more
     // than cap / 2 tiles) + one that holds every tile a frame can have (>= 1 point each).  No list can overflow.
     sl.tiles_cap = cap + 2u;
@@ -350,6 +350,23 @@ static gm_status enqueue_launches(gm_ctx *ctx, Slot &sl, const RowLayout &rows, 
     // (getLocalFrame's scatter terms are summed by the compaction: one partial row per kCpTile cropped points)
     uint32_t row_tile = kCpTile;
     const uint32_t nparts = launch_compact_valid(sl, ns, cf.weightingFactor, s, &row_tile);
+    bool cloud_copy_pending = false;
+    if (sl.cloud_out && n) {
+        // /choppedCloud to the caller's page-locked rows: the valid cloud is final here.  The number of valid points is
+        // only known on the device, so the copy takes the frame's n rows (>= n_valid; the host reads the first n_valid).
+        // On its own stream it overlaps everything that follows; inside a captured graph it stays in line.
+        const size_t bytes = (size_t)n * sizeof(float4);
+        if (sl.capturing) {   // (a captured copy's size is frozen: the bucketed size, as far as the buffer has rows -- both >= n)
+            const size_t frozen = (size_t)(ns < sl.cloud_out_cap ? ns : sl.cloud_out_cap) * sizeof(float4);
+            GM_HIP(ctx, hipMemcpyAsync(sl.cloud_out, sl.valid4, frozen, hipMemcpyDeviceToHost, s));
+        } else {
+            GM_HIP(ctx, hipEventRecord(sl.ev_valid, s));
+            GM_HIP(ctx, hipStreamWaitEvent(sl.copy_stream, sl.ev_valid, 0));
+            GM_HIP(ctx, hipMemcpyAsync(sl.cloud_out, sl.valid4, bytes, hipMemcpyDeviceToHost, sl.copy_stream));
+            GM_HIP(ctx, hipEventRecord(sl.ev_copied, sl.copy_stream));
+            cloud_copy_pending = true;
+        }
+    }
     record(ctx, sl, 4);
     record(ctx, sl, 5);
     sl.vox_sort_path = (cf.flags & GM_CFG_VOXEL_GRID) && !vd.enabled;
@@ -374,6 +391,7 @@ static gm_status enqueue_launches(gm_ctx *ctx, Slot &sl, const RowLayout &rows, 
     record(ctx, sl, 7);
     if (!(cf.flags & (GM_CFG_RANSAC_PLANE | GM_CFG_RANSAC_CYLINDER)))
         launch_frame_finalize(sl.tile_partials, nparts, row_tile, sl, s);
+    if (cloud_copy_pending) GM_HIP(ctx, hipStreamWaitEvent(s, sl.ev_copied, 0));   // the slot's stream ends behind the cloud copy
     GM_HIP(ctx, hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(FrameOut), hipMemcpyDeviceToHost, s));
     return GM_OK;
 }
@@ -385,6 +403,7 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
     const size_t raw_bytes = (size_t)n * cloud->point_step;
     const bool on_dev = (cloud->flags & GM_CLOUD_DEVICE) != 0;
     if (n && !cloud->data) return fail(ctx, GM_ERR_INVALID_ARG, "gm_cloud.data is NULL");
+    if (sl.cloud_out && n > sl.cloud_out_cap) return fail(ctx, GM_ERR_CAPACITY, "gm_set_cloud_output: the frame has more points than the cloud buffer has rows");
     gm_status st = check_layout(ctx, cloud);
     if (st != GM_OK) return st;
     // n == 0 still sizes the buffers for one point: every stage below may then assume non-null scratch (an empty
@@ -462,10 +481,10 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
         unsigned char key[sizeof(sl.graph_key[0])];
         uint32_t klen = 0;
         auto put = [&](const void *p, size_t len) { memcpy(key + klen, p, len); klen += (uint32_t)len; };
-        static_assert(sizeof(RowLayout) + sizeof(GridParams) + sizeof(VoxDense) + 64 <= sizeof(sl.graph_key[0]), "graph key");
+        static_assert(sizeof(RowLayout) + sizeof(GridParams) + sizeof(VoxDense) + 80 <= sizeof(sl.graph_key[0]), "graph key");
         memset(key, 0, sizeof(key));
         put(&ns, 4); put(&sl.alloc_gen, 4); put(&rows, sizeof(rows)); put(&g, sizeof(g)); put(&vd, sizeof(vd));
-        put(&cf.flags, 4); put(&ctx->own_lo, 8); put(&ctx->own_hi, 8);
+        put(&cf.flags, 4); put(&ctx->own_lo, 8); put(&ctx->own_hi, 8); put(&sl.cloud_out, sizeof(sl.cloud_out)); put(&sl.cloud_out_cap, 4);
         int gi = -1, victim = -1;   // victim: an empty entry if there is one, else the least recently used
         for (int k = 0; k < Slot::kGraphs; ++k) {
             if (sl.graph_exec[k] && sl.graph_key_len[k] == klen && memcmp(key, sl.graph_key[k], klen) == 0) gi = k;
@@ -648,22 +667,22 @@ gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap, uint32_t scat
     if (do_plane) {
         uint8_t *lab = first ? nullptr : sl.labels;
         launch_plane_hypotheses(sl.valid4, lab, 0, n_ptr, n_cap, cf.ransac_seed, H, sl.hyp_plane, sl.cnt_plane, s);
-        const uint32_t *fsel = nullptr; const int32_t *fcnt = nullptr; uint32_t fk = 0;
+        const uint32_t *fsel = nullptr; const int32_t *fcnt = nullptr; uint32_t fk = 0; bool fmask = false;
         launch_score_preemptive(0, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_plane, sl.band, H, cf.ransac_threshold,
-                                sl.score_partial, sl.cnt_plane, sl.best_plane, true, &fsel, &fcnt, &fk, s);
+                                sl.score_partial, sl.cnt_plane, sl.best_plane, true, &fsel, &fcnt, &fk, s, sl.inl_mask, &fmask);
         mom_rows = launch_label(0, sl.valid4, sl.labels, 0, 1, n_ptr, n_cap, sl.hyp_plane, sl.band, sl.best_plane,
-                                cf.ransac_threshold, first ? 1 : 0, fsel, fcnt, fk, s, sl.vnorm4, sl.mom_partial);
+                                cf.ransac_threshold, first ? 1 : 0, fsel, fcnt, fk, s, sl.vnorm4, sl.mom_partial, fmask ? sl.inl_mask : nullptr);
         first = false;
     }
     if (do_cyl) {
         uint8_t *lab = first ? nullptr : sl.labels;
         launch_cylinder_hypotheses(sl.valid4, sl.vnorm4, lab, 0, n_ptr, n_cap, cf.ransac_seed + 1, H, sl.hyp_cyl,
                                    sl.cnt_cyl, sl.band, cf.ransac_threshold, s);
-        const uint32_t *fsel = nullptr; const int32_t *fcnt = nullptr; uint32_t fk = 0;
+        const uint32_t *fsel = nullptr; const int32_t *fcnt = nullptr; uint32_t fk = 0; bool fmask = false;
         launch_score_preemptive(1, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_cyl, sl.band, H, cf.ransac_threshold,
-                                sl.score_partial, sl.cnt_cyl, sl.best_cyl, true, &fsel, &fcnt, &fk, s);
+                                sl.score_partial, sl.cnt_cyl, sl.best_cyl, true, &fsel, &fcnt, &fk, s, sl.inl_mask, &fmask);
         mom_rows = launch_label(1, sl.valid4, sl.labels, 0, 2, n_ptr, n_cap, sl.hyp_cyl, sl.band, sl.best_cyl,
-                                cf.ransac_threshold, first ? 1 : 0, fsel, fcnt, fk, s, sl.vnorm4, sl.mom_partial);
+                                cf.ransac_threshold, first ? 1 : 0, fsel, fcnt, fk, s, sl.vnorm4, sl.mom_partial, fmask ? sl.inl_mask : nullptr);
         first = false;
     }
     // the label passes left the moments of their segments in sl.mom_partial (one row per block, the same grid for both
@@ -778,6 +797,9 @@ gm_status gm_create(const gm_config *cfg, gm_ctx **out)
             for (int k = 0; k <= GM_N_STAGES; ++k) GM_HIP(ctx, hipEventCreate(&sl.ev[k]));
             GM_HIP(ctx, hipEventCreate(&sl.ev_k0));
             GM_HIP(ctx, hipEventCreate(&sl.ev_k1));
+            GM_HIP(ctx, hipStreamCreateWithFlags(&sl.copy_stream, hipStreamNonBlocking));
+            GM_HIP(ctx, hipEventCreateWithFlags(&sl.ev_valid, hipEventDisableTiming));
+            GM_HIP(ctx, hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming));
             GM_HIP(ctx, dmalloc(sl.ctr, 1));
             GM_HIP(ctx, dmalloc(sl.voxp, 1));
             GM_HIP(ctx, dmalloc(sl.d_out, 1));
@@ -831,6 +853,9 @@ void gm_destroy(gm_ctx *ctx)
             for (int k = 0; k <= GM_N_STAGES; ++k) if (sl.ev[k]) hipEventDestroy(sl.ev[k]);
             if (sl.ev_k0) hipEventDestroy(sl.ev_k0);
             if (sl.ev_k1) hipEventDestroy(sl.ev_k1);
+            if (sl.copy_stream) { hipStreamSynchronize(sl.copy_stream); hipStreamDestroy(sl.copy_stream); }
+            if (sl.ev_valid) hipEventDestroy(sl.ev_valid);
+            if (sl.ev_copied) hipEventDestroy(sl.ev_copied);
             if (sl.stream) hipStreamDestroy(sl.stream);
         }
         delete[] ctx->slots;
@@ -867,6 +892,40 @@ gm_status gm_wait_frame(gm_ctx *ctx, uint32_t slot, gm_frame_result *res)
     gm_status st = check_slot(ctx, slot);
     if (st != GM_OK) return st;
     if (res) *res = ctx->slots[slot].last;
+    return GM_OK;
+}
+
+gm_status gm_poll_frame(gm_ctx *ctx, uint32_t slot)
+{
+    if (!ctx) return GM_ERR_INVALID_ARG;
+    if (slot >= ctx->n_slots) return fail(ctx, GM_ERR_INVALID_ARG, "slot out of range");
+    Slot &sl = ctx->slots[slot];
+    if (!sl.submitted) return GM_ERR_NOT_READY;   // (not an error worth a message: the caller is asking)
+    if (sl.complete) return GM_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, GM_ERR_DEVICE, "hipSetDevice failed");
+    const hipError_t e = hipStreamQuery(sl.stream);   // (the stream ends behind the cloud copy, if there is one)
+    if (e == hipSuccess) return GM_OK;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return GM_ERR_NOT_READY; }
+    ctx->err = std::string("hipStreamQuery: ") + hipGetErrorString(e);
+    return GM_ERR_DEVICE;
+}
+
+gm_status gm_set_cloud_output(gm_ctx *ctx, uint32_t slot, float *xyzw, uint32_t capacity)
+{
+    if (!ctx) return GM_ERR_INVALID_ARG;
+    if (slot >= ctx->n_slots) return fail(ctx, GM_ERR_INVALID_ARG, "slot out of range");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, GM_ERR_DEVICE, "hipSetDevice failed");
+    Slot &sl = ctx->slots[slot];
+    if (sl.submitted && !sl.complete) GM_HIP(ctx, hipStreamSynchronize(sl.stream));   // a frame in flight still writes the old buffer
+    if (xyzw) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, xyzw) != hipSuccess || a.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            return fail(ctx, GM_ERR_INVALID_ARG, "gm_set_cloud_output: the buffer must be page-locked memory from gm_host_alloc");
+        }
+    }
+    sl.cloud_out = reinterpret_cast<float4 *>(xyzw);
+    sl.cloud_out_cap = xyzw ? capacity : 0u;
     return GM_OK;
 }
 

@@ -803,6 +803,17 @@ gm_status gm_group_submit_frame(gm_group *grp, const gm_cloud *cloud)
     return gfail(grp, GM_ERR_NOT_READY, "gm_group_submit_frame: no free slot");
 }
 
+gm_status gm_group_poll_frame(gm_group *grp)
+{
+    if (!grp) return GM_ERR_INVALID_ARG;
+    gm_group &G = *grp;
+    if (G.inflight.empty()) return GM_ERR_NOT_READY;
+    const gm_group::Ticket t = G.inflight.front();
+    const gm_status st = gm_poll_frame(G.ctx[t.rank], t.slot);
+    if (st != GM_OK && st != GM_ERR_NOT_READY) return gfail(grp, st, std::string("rank ") + std::to_string(t.rank) + ": " + gm_last_error(G.ctx[t.rank]));
+    return st;
+}
+
 gm_status gm_group_wait_frame(gm_group *grp, gm_frame_result *res, uint32_t *rank_out, uint32_t *slot_out)
 {
     if (!grp) return GM_ERR_INVALID_ARG;

@@ -80,6 +80,7 @@ struct Slot {
     double *partials = nullptr;   // [kScatterBlocks][6]  (gm_get_local_frame on caller-supplied normals)
     double *tile_partials = nullptr;  // [compact_blocks(cap)][6]  scatter rows left by the NaN-normal compaction
     uint8_t *labels = nullptr;
+    uint8_t *inl_mask = nullptr;   // per valid point: which of the last RANSAC stage's hypotheses it is an inlier of
     DevCounters *ctr = nullptr;
     VoxelParams *voxp = nullptr;
     FrameOut *d_out = nullptr;
@@ -95,6 +96,11 @@ struct Slot {
     double *mom_plane = nullptr, *mom_cyl = nullptr;  // [16]
     unsigned long long *nn_best = nullptr;            // [cap]
     float4 *vox_nrm4 = nullptr;                       // [cap] normal of each voxel centroid's nearest point (GM_CFG_NEAREST)
+    // /choppedCloud output (gm_set_cloud_output): caller-owned page-locked rows, copied on a stream of their own
+    float4 *cloud_out = nullptr;
+    uint32_t cloud_out_cap = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_valid = nullptr, ev_copied = nullptr;
     // state
     bool submitted = false, complete = false;
     bool vox_sort_path = false;  // this frame's voxels came from the sort path (may report passthrough)
@@ -196,11 +202,13 @@ void launch_score(int model, const float4 *pts, const uint8_t *labels, uint32_t 
 bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels, uint32_t want,
                              const uint32_t *n_ptr, uint32_t n_cap, const float *hyp8, float2 *band, uint32_t H,
                              double tau, uint32_t *scratch, int32_t *counts, uint32_t *best, bool prepared,
-                             const uint32_t **sel_out, const int32_t **cnt_out, uint32_t *k_out, hipStream_t s);
+                             const uint32_t **sel_out, const int32_t **cnt_out, uint32_t *k_out, hipStream_t s,
+                             uint8_t *masks = nullptr, bool *masks_written = nullptr);   // masks: the last stage streams and leaves every point's inlier mask there
 uint32_t launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, uint32_t label, const uint32_t *n_ptr,
                       uint32_t n_cap, const float *hyp8, const float2 *band, uint32_t *best, double tau, int init,
                       const uint32_t *sel, const int32_t *counts_k, uint32_t K, hipStream_t s,
-                      const float4 *nrm = nullptr, double *mom_partial = nullptr);  // returns the grid size (= partial rows)
+                      const float4 *nrm = nullptr, double *mom_partial = nullptr,
+                      const uint8_t *masks = nullptr);  // returns the grid size (= partial rows); masks: of the K hypotheses in sel
 void launch_segment_moments(const float4 *pts, const float4 *nrm, const uint8_t *labels, uint32_t label,
                             const uint32_t *n_ptr, uint32_t n_cap, double *partial, double *mom16, hipStream_t s);
 void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, const float *hyp_cyl,

@@ -549,10 +549,86 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
 }
 
 
+// ---- the LAST stage: K <= 8 hypotheses on EVERY point, as a stream -------------------------------------------------------
+// lane <-> point (one coalesced 16-byte load per lane, kStPer points per lane in flight), the K hypotheses wave-uniform
+// in scalar registers, per hypothesis one compare chain, one ballot and one popcount into a scalar counter; a block adds
+// its K counters with one integer atomic each.  The stage also leaves, per point, the K-bit mask of the hypotheses it is
+// an inlier of (1 byte): the label pass reads masks and touches the rows of inliers only.  HBM-bound: 16 B read + 1 B
+// written per point.  (lane <-> hypothesis over LDS-staged points -- k_score_sel, the shape of the stages with 1024 / 128
+// hypotheses -- scored these 8 at 17-22 % of the memory roofline on the 10 M-point frame: bound by neither.)
+constexpr int kStThreads = 256, kStPer = 4, kStK = 8;
+template <int MODEL>
+__global__ __launch_bounds__(kStThreads) void k_score_stream(const float4 *__restrict__ pts, const uint8_t *__restrict__ labels,
+                                                             uint32_t want, const uint32_t *__restrict__ n_ptr, uint32_t n_host,
+                                                             const float *__restrict__ hyp8, const float2 *__restrict__ band,
+                                                             const uint32_t *__restrict__ sel, uint32_t K, float tau,
+                                                             int32_t *__restrict__ counts_k, uint8_t *__restrict__ masks)
+{
+    __shared__ uint32_t red[kStThreads / kWave][kStK];
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    // the hypotheses (uniform addresses: scalar loads); slots past K score nothing
+    float h[kStK][8];
+#pragma unroll
+    for (int k = 0; k < kStK; ++k) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) h[k][q] = 0.f;
+        h[k][0] = __builtin_nanf("");
+        if ((uint32_t)k < K) {
+            const uint32_t hi = sel[k];
+            const float *hy = hyp8 + 8 * (size_t)hi;
+            h[k][0] = hy[0]; h[k][1] = hy[1]; h[k][2] = hy[2]; h[k][3] = hy[3];
+            if (MODEL == 1) { const float2 bd = band[hi]; h[k][4] = hy[4]; h[k][5] = hy[5]; h[k][6] = bd.x; h[k][7] = bd.y; }
+        }
+    }
+    uint32_t cnt[kStK];
+#pragma unroll
+    for (int k = 0; k < kStK; ++k) cnt[k] = 0u;
+    const uint32_t span = (uint32_t)(kStThreads * kStPer);
+    for (uint32_t base = blockIdx.x * span; base < n; base += gridDim.x * span) {   // uniform per block
+        float4 p[kStPer];
+        bool ok[kStPer];
+#pragma unroll
+        for (int u = 0; u < kStPer; ++u) {
+            const uint32_t i = base + (uint32_t)u * kStThreads + threadIdx.x;
+            ok[u] = i < n;
+            if (ok[u] && labels) ok[u] = labels[i] == want;
+            p[u] = pts[i < n ? i : n - 1u];
+        }
+#pragma unroll
+        for (int u = 0; u < kStPer; ++u) {
+            const uint32_t i = base + (uint32_t)u * kStThreads + threadIdx.x;
+            uint32_t m = 0;
+#pragma unroll
+            for (int k = 0; k < kStK; ++k) {
+                const bool in = ok[u] && (MODEL == 0 ? plane_inlier(p[u].x, p[u].y, p[u].z, h[k][0], h[k][1], h[k][2], h[k][3], tau)
+                                                     : cyl_inlier(p[u].x, p[u].y, p[u].z, h[k][0], h[k][1], h[k][2], h[k][3], h[k][4],
+                                                                  h[k][5], h[k][6], h[k][7]));
+                cnt[k] += (uint32_t)__popcll(__ballot(in));   // wave-uniform
+                m |= in ? (1u << k) : 0u;
+            }
+            if (i < n) masks[i] = (uint8_t)m;
+        }
+    }
+    const int w = threadIdx.x / kWave;
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int k = 0; k < kStK; ++k) red[w][k] = cnt[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int j = 0; j < kStThreads / kWave; ++j) t += red[j][threadIdx.x];
+        if (t) atomicAdd(&counts_k[threadIdx.x], (int32_t)t);
+    }
+}
+
 // init != 0: this is the first model of the frame -- every point is eligible and labels are WRITTEN for all
 // points (no memset of the label array is needed); otherwise only points with labels == want are touched.
 // counts_k != nullptr: the winner is taken from the K re-scored hypotheses (largest count, lowest hypothesis index
 // on ties) by every block for itself, and block 0 publishes it in best[0..1].
+// masks != nullptr (with counts_k): the last scoring stage left every point's K-bit inlier mask (k_score_stream): the pass
+// reads the winner's bit instead of the row, and loads rows (and normals) of inliers only.
 // MOM (frame pipeline): the pass also sums the moments of the segment it labels -- count, sum p, sum pp^T and, for the
 // cylinder, sum nn^T, in fp64 -- into mom_partial[MODEL][block][16]: the points are in registers anyway, so the
 // separate pass over labels + points + normals (33 B per point for 13 algorithmic) is gone; normals are only loaded
@@ -564,24 +640,26 @@ __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, u
                                                const float2 *__restrict__ band, uint32_t *__restrict__ best,
                                                float tau, int init, const int32_t *__restrict__ counts_k,
                                                const uint32_t *__restrict__ sel, uint32_t K,
-                                               const float4 *__restrict__ nrm, double *__restrict__ mom_partial)
+                                               const float4 *__restrict__ nrm, double *__restrict__ mom_partial,
+                                               const uint8_t *__restrict__ masks)
 {
     const uint32_t n = n_ptr ? *n_ptr : n_host;
-    uint32_t h;
+    uint32_t h, wbit = 0;
     if (counts_k) {
-        __shared__ uint32_t win[2];
+        __shared__ uint32_t win[3];
         if (threadIdx.x < kWave) {
-            uint32_t c = 0, hi = 0xFFFFFFFFu;
+            uint32_t c = 0, hi = 0xFFFFFFFFu, sl = threadIdx.x;
             if (threadIdx.x < K) { c = (uint32_t)counts_k[threadIdx.x]; hi = sel[threadIdx.x]; }
 #pragma unroll
             for (int o = 1; o < kWave; o <<= 1) {
-                const uint32_t oc = __shfl_xor(c, o, kWave), oh = __shfl_xor(hi, o, kWave);
-                if (oh != 0xFFFFFFFFu && (hi == 0xFFFFFFFFu || oc > c || (oc == c && oh < hi))) { c = oc; hi = oh; }
+                const uint32_t oc = __shfl_xor(c, o, kWave), oh = __shfl_xor(hi, o, kWave), os = __shfl_xor(sl, o, kWave);
+                if (oh != 0xFFFFFFFFu && (hi == 0xFFFFFFFFu || oc > c || (oc == c && oh < hi))) { c = oc; hi = oh; sl = os; }
             }
-            if (threadIdx.x == 0) { win[0] = hi; win[1] = c; }
+            if (threadIdx.x == 0) { win[0] = hi; win[1] = c; win[2] = sl; }
         }
         __syncthreads();
         h = win[0];
+        wbit = win[2] & 7u;
         if (blockIdx.x == 0 && threadIdx.x == 0) { best[0] = win[0]; best[1] = win[1]; }
     } else {
         h = best[0];
@@ -600,11 +678,20 @@ __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, u
     double m[NM];
 #pragma unroll
     for (int k = 0; k < NM; ++k) m[k] = 0.0;
+    const bool by_mask = masks != nullptr && counts_k != nullptr;   // uniform
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const bool take = init || labels[i] == want;
-        const float4 p = pts[i];
-        const bool in = take && (MODEL == 0 ? plane_inlier(p.x, p.y, p.z, a, b, c, d, tau)
-                                            : cyl_inlier(p.x, p.y, p.z, a, b, c, d, e, f, lo2, hi2));
+        bool in;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (by_mask) {
+            // (the mask was taken over the points eligible at scoring time -- labels == want -- and no label has changed since)
+            in = ((masks[i] >> wbit) & 1u) != 0u;
+            if (MOM && in) p = pts[i];
+        } else {
+            const bool take = init || labels[i] == want;
+            p = pts[i];
+            in = take && (MODEL == 0 ? plane_inlier(p.x, p.y, p.z, a, b, c, d, tau)
+                                     : cyl_inlier(p.x, p.y, p.z, a, b, c, d, e, f, lo2, hi2));
+        }
         if (init) labels[i] = in ? (uint8_t)label : (uint8_t)0;
         else if (in) labels[i] = (uint8_t)label;
         if (MOM && in) {
@@ -860,8 +947,10 @@ static void select_topk(const int32_t *counts, const uint32_t *ids, uint32_t M, 
 bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels, uint32_t want,
                              const uint32_t *n_ptr, uint32_t n_cap, const float *hyp8, float2 *band, uint32_t H,
                              double tau, uint32_t *scratch, int32_t *counts, uint32_t *best, bool prepared,
-                             const uint32_t **sel_out, const int32_t **cnt_out, uint32_t *k_out, hipStream_t s)
+                             const uint32_t **sel_out, const int32_t **cnt_out, uint32_t *k_out, hipStream_t s, uint8_t *masks,
+                             bool *masks_written)
 {
+    if (masks_written) *masks_written = false;
     if (H <= (uint32_t)kPre2Keep) {  // nothing to pre-select
         launch_score(model, pts, labels, want, n_ptr, n_cap, hyp8, band, H, tau, nullptr, counts, best, s);
         return false;
@@ -893,6 +982,22 @@ bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels
         if (model == 0) score_stage_all<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre2Stride, counts, n2, s);
         else score_stage_all<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre2Stride, counts, n2, s);
     }
+    static const char *fs = getenv("GM_RANSAC_FINAL");   // "sel": the last stage in the lane <-> hypothesis shape (A/B timing)
+    if (masks && K2 <= (uint32_t)kStK && !(fs && fs[0] == 's')) {
+        // the last stage streams: lane <-> point, hypotheses in scalar registers (k_score_stream); also leaves the inlier masks
+        uint32_t nb = (n_cap + kStThreads * kStPer - 1) / (kStThreads * kStPer);
+        if (nb > 8192u) nb = 8192u;
+        if (nb == 0) nb = 1;
+        if (model == 0)
+            hipLaunchKernelGGL(k_score_stream<0>, dim3(nb), dim3(kStThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8, cb,
+                               (const uint32_t *)selB, K2, (float)tau, cntB, masks);
+        else
+            hipLaunchKernelGGL(k_score_stream<1>, dim3(nb), dim3(kStThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8, cb,
+                               (const uint32_t *)selB, K2, (float)tau, cntB, masks);
+        *sel_out = selB; *cnt_out = cntB; *k_out = K2;
+        if (masks_written) *masks_written = true;
+        return true;
+    }
     if (model == 0) score_stage_sel<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selB, K2, tau, 1u, cntB, none, s);
     else score_stage_sel<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selB, K2, tau, 1u, cntB, none, s);
     *sel_out = selB; *cnt_out = cntB; *k_out = K2;
@@ -902,7 +1007,7 @@ bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels
 uint32_t launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, uint32_t label, const uint32_t *n_ptr,
                       uint32_t n_cap, const float *hyp8, const float2 *band, uint32_t *best, double tau, int init,
                       const uint32_t *sel, const int32_t *counts_k, uint32_t K, hipStream_t s, const float4 *nrm,
-                      double *mom_partial)
+                      double *mom_partial, const uint8_t *masks)
 {
     // counts_k != nullptr: winner = best of the K (<= 64) finally re-scored hypotheses in (sel[K], counts_k[K])
     uint32_t nb = (n_cap + 255) / 256;
@@ -918,7 +1023,7 @@ uint32_t launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t wa
     if (nb == 0) nb = 1;
 #define GM_LABEL(M, MO)                                                                                                 \
     hipLaunchKernelGGL((k_label<M, MO>), dim3(nb), dim3(256), 0, s, pts, labels, want, label, n_ptr, n_cap, hyp8, band, \
-                       best, (float)tau, init, counts_k, sel, K, nrm, mom_partial)
+                       best, (float)tau, init, counts_k, sel, K, nrm, mom_partial, masks)
     if (model == 0) { if (mom_partial) GM_LABEL(0, 1); else GM_LABEL(0, 0); }
     else { if (mom_partial) GM_LABEL(1, 1); else GM_LABEL(1, 0); }
 #undef GM_LABEL

@@ -110,6 +110,36 @@ int main(int argc, char **argv)
             }
             REQUIRE(done == 4);
         }
+        // --- the node's streaming loop (ros/geometric_mapping_node.cpp): page-locked /choppedCloud rows, and every frame
+        // taken off the pipeline by a completion query -- at the top of each "callback", then until the pipeline is
+        // empty -- never by waiting for it to fill.  Frames come back in order, each the blocking frame bit for bit.
+        {
+            std::vector<int> devs(1, 0);
+            Processor ps(5.0, 0.5, 0.5, 0.2, devs, GM_CFG_DEFAULT, 2);
+            ps.enableCloudOutput((unsigned)n / 4);            // too small on purpose: grown by the first frame
+            const unsigned total = 12;
+            unsigned submitted = 0, done = 0, polls = 0;
+            while (done < total) {
+                gm_frame_result rs;
+                while (ps.tryWaitFrame(rs)) {                 // publish what has finished
+                    const unsigned want = done % 2 ? (unsigned)(n / 2) : (unsigned)n;
+                    REQUIRE(rs.n_in == want);
+                    const PointCloud pc = ps.choppedCloud();  // (from the page-locked rows)
+                    REQUIRE(pc.size() == rs.n_valid);
+                    if (want == (unsigned)n) {
+                        REQUIRE(rs.n_valid == r.n_valid && std::memcmp(rs.scatter, r.scatter, sizeof(r.scatter)) == 0);
+                        REQUIRE(std::memcmp(&pc[0], &chopped[0], chopped.size() * sizeof(PointXYZ)) == 0);
+                    }
+                    ++done;
+                }
+                if (submitted < total && ps.inFlight() < ps.capacity()) {
+                    ps.submitFrame(&rows[0], submitted % 2 ? (unsigned)(n / 2) : (unsigned)n, step, 0, 4, 8);
+                    ++submitted;
+                }
+                REQUIRE(++polls < 100000000u);                // (a frame that never finishes)
+            }
+            REQUIRE(ps.inFlight() == 0 && !ps.tryWaitFrame(r) && r.n_in == (unsigned)n);   // nothing in flight: false, result untouched
+        }
         // error conventions: a status, never a crash
         bool threw = false;
         try { proc.getLocalFrame((int)cloudNormals.size() + 1, 0.2, cloudNormals, eigenVals, eigenVecs); } catch (const std::out_of_range &) { threw = true; }

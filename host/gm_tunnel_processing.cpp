@@ -21,6 +21,7 @@ Processor::Processor(double b, double leaf, double r, double wf, int device, uns
     gm_status s = gm_create(&cfg, &ctx_);
     if (s != GM_OK) throw Error(s, std::string("gm_create: ") + gm_last_error(0));
     cur_ = ctx_;
+    std::memset(&last_, 0, sizeof(last_));
 }
 
 Processor::Processor(double b, double leaf, double r, double wf, const std::vector<int> &devices, unsigned flags,
@@ -37,12 +38,46 @@ Processor::Processor(double b, double leaf, double r, double wf, const std::vect
     if (s != GM_OK) throw Error(s, std::string("gm_group_create: ") + gm_group_last_error(0));
     ctx_ = gm_group_ctx(grp_, 0);
     cur_ = ctx_;
+    std::memset(&last_, 0, sizeof(last_));
 }
 
 Processor::~Processor()
 {
+    for (size_t i = 0; i < cloud_bufs_.size(); ++i) {   // (gm_set_cloud_output waits for a frame that still writes the rows)
+        gm_set_cloud_output(cloud_bufs_[i].ctx, cloud_bufs_[i].slot, 0, 0);
+        gm_host_free(cloud_bufs_[i].ctx, cloud_bufs_[i].rows);
+    }
     if (grp_) gm_group_destroy(grp_);   // (owns the contexts)
     else gm_destroy(ctx_);
+}
+
+void Processor::enableCloudOutput(unsigned max_points)
+{
+    if (cloud_bufs_.empty()) {
+        const unsigned ranks = grp_ ? gm_group_size(grp_) : 1u;
+        for (unsigned r = 0; r < ranks; ++r)
+            for (unsigned s = 0; s < n_slots_; ++s) {
+                CloudBuf b = {grp_ ? gm_group_ctx(grp_, r) : ctx_, s, 0, 0u};
+                cloud_bufs_.push_back(b);
+            }
+    }
+    growCloudOutput(max_points ? max_points : 1u);
+}
+
+void Processor::growCloudOutput(unsigned n_points)
+{
+    for (size_t i = 0; i < cloud_bufs_.size(); ++i) {
+        CloudBuf &b = cloud_bufs_[i];
+        if (b.cap >= n_points) continue;
+        const unsigned cap = n_points + n_points / 4u;
+        void *rows = 0;
+        gm_status s = gm_host_alloc(b.ctx, (size_t)cap * 16u, &rows);
+        if (s != GM_OK) throw Error(s, std::string("enableCloudOutput: ") + gm_last_error(b.ctx));
+        s = gm_set_cloud_output(b.ctx, b.slot, (float *)rows, cap);   // (waits for the slot's frame in flight, if any)
+        if (s != GM_OK) { gm_host_free(b.ctx, rows); throw Error(s, std::string("enableCloudOutput: ") + gm_last_error(b.ctx)); }
+        if (b.rows) gm_host_free(b.ctx, b.rows);
+        b.rows = (float *)rows; b.cap = cap;
+    }
 }
 
 unsigned Processor::capacity() const { return grp_ ? gm_group_size(grp_) * n_slots_ : n_slots_; }
@@ -51,6 +86,7 @@ unsigned Processor::inFlight() const { return grp_ ? gm_group_in_flight(grp_) : 
 void Processor::submitFrame(const void *rows, unsigned n, unsigned step, unsigned ox, unsigned oy, unsigned oz, bool bigendian)
 {
     gm_cloud c = {rows, n, step, ox, oy, oz, bigendian ? GM_CLOUD_BIGENDIAN : 0u};
+    if (!cloud_bufs_.empty()) growCloudOutput(n);
     if (grp_) {
         gm_status s = gm_group_submit_frame(grp_, &c);
         if (s != GM_OK) throw Error(s, std::string("submitFrame: ") + gm_group_last_error(grp_));
@@ -71,14 +107,33 @@ gm_frame_result Processor::waitFrame()
         if (s != GM_OK) throw Error(s, std::string("waitFrame: ") + gm_group_last_error(grp_));
         cur_ = gm_group_ctx(grp_, rank);
         cur_slot_ = slot;
+        last_ = r;
         return r;
     }
     if (!pending_) throw Error(GM_ERR_NOT_READY, "waitFrame: no frame in flight");
     const unsigned slot = (next_slot_ + n_slots_ - pending_) % n_slots_;   // the oldest
+    --pending_;   // (the frame leaves the queue whatever the wait returns: a failed frame must not be waited for again)
     check(gm_wait_frame(ctx_, slot, &r), "waitFrame");
-    --pending_;
     cur_ = ctx_; cur_slot_ = slot;
+    last_ = r;
     return r;
+}
+
+bool Processor::tryWaitFrame(gm_frame_result &result)
+{
+    gm_status s;
+    if (grp_) {
+        if (!gm_group_in_flight(grp_)) return false;
+        s = gm_group_poll_frame(grp_);
+        if (s != GM_OK && s != GM_ERR_NOT_READY) throw Error(s, std::string("tryWaitFrame: ") + gm_group_last_error(grp_));
+    } else {
+        if (!pending_) return false;
+        s = gm_poll_frame(ctx_, (next_slot_ + n_slots_ - pending_) % n_slots_);
+        if (s != GM_OK && s != GM_ERR_NOT_READY) check(s, "tryWaitFrame");
+    }
+    if (s != GM_OK) return false;
+    result = waitFrame();
+    return true;
 }
 
 PointCloud Processor::chopCloud(const double &bound, const PointCloud &cloud)
@@ -146,14 +201,23 @@ gm_frame_result Processor::processFrame(const void *rows, unsigned n, unsigned s
         return waitFrame();
     }
     gm_cloud c = {rows, n, step, ox, oy, oz, bigendian ? GM_CLOUD_BIGENDIAN : 0u};
+    if (!cloud_bufs_.empty()) growCloudOutput(n);
     gm_frame_result r;
     check(gm_process_frame(ctx_, &c, &r), "processFrame");
     cur_ = ctx_; cur_slot_ = 0;
+    last_ = r;
     return r;
 }
 
 PointCloud Processor::choppedCloud()
 {
+    for (size_t i = 0; i < cloud_bufs_.size(); ++i) {   // the rows are already on the host (enableCloudOutput)
+        const CloudBuf &b = cloud_bufs_[i];
+        if (b.ctx != cur_ || b.slot != cur_slot_ || !b.rows) continue;
+        PointCloud out(last_.n_valid);
+        if (last_.n_valid) std::memcpy(&out[0].x, b.rows, (size_t)last_.n_valid * sizeof(PointXYZ));
+        return out;
+    }
     uint32_t n = 0;
     gm_status s = gm_get_cropped_xyz(cur_, cur_slot_, 0, 0, &n);
     if (s != GM_OK && s != GM_ERR_CAPACITY) check(s, "choppedCloud");

@@ -71,6 +71,15 @@ public:
     void submitFrame(const void *rows, unsigned n_points, unsigned point_step, unsigned off_x, unsigned off_y, unsigned off_z,
                      bool bigendian = false);   // the rows may be released on return
     gm_frame_result waitFrame();      // the oldest frame in flight; the accessors below then refer to it
+    // the same without blocking: false (and `result` untouched) while the oldest frame in flight is still running or when
+    // nothing is in flight (gm_poll_frame / gm_group_poll_frame).  The reference publishes each frame inside its own
+    // callback (src/geometric_mapping.cpp:100-117); a host with frames in flight calls this at the top of every
+    // callback and from a timer, and publishes whatever has finished.
+    bool tryWaitFrame(gm_frame_result &result);
+    // /choppedCloud straight into page-locked host rows (gm_set_cloud_output): one buffer per slot of every device, each
+    // with room for max_points rows (grown when a larger frame is submitted).  The copy overlaps the tail of the frame;
+    // choppedCloud() then reads those rows instead of fetching the cloud from the device.
+    void enableCloudOutput(unsigned max_points);
 
     // ---- tunnel_processing.hpp:38-54 ----
     PointCloud chopCloud(const double &bound, const PointCloud &cloud);
@@ -117,6 +126,10 @@ private:
     gm_ctx *cur_;          // where the last completed frame's bulky outputs live ...
     unsigned cur_slot_;    // ... and in which slot
     unsigned n_slots_, next_slot_, pending_;   // single device: ring of slots
+    gm_frame_result last_;                     // of the frame the accessors refer to
+    struct CloudBuf { gm_ctx *ctx; unsigned slot; float *rows; unsigned cap; };
+    std::vector<CloudBuf> cloud_bufs_;         // enableCloudOutput: one per (device, slot)
+    void growCloudOutput(unsigned n_points);
     Processor(const Processor &);
     Processor &operator=(const Processor &);
 };

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GM_ABI_VERSION 2u
+#define GM_ABI_VERSION 3u
 
 typedef struct gm_ctx gm_ctx; /* opaque */
 
@@ -157,6 +157,20 @@ gm_status gm_process_frame(gm_ctx *ctx, const gm_cloud *cloud, gm_frame_result *
  * buffer may be reused as soon as submit returns. */
 gm_status gm_submit_frame(gm_ctx *ctx, uint32_t slot, const gm_cloud *cloud);
 gm_status gm_wait_frame(gm_ctx *ctx, uint32_t slot, gm_frame_result *res);
+/* Completion query, never blocks: GM_OK when the slot's submitted frame has finished (gm_wait_frame will return at once),
+ * GM_ERR_NOT_READY while it is still running or when the slot holds no submitted frame.  The reference publishes every
+ * frame inside its own callback (src/geometric_mapping.cpp:100-117); a host that keeps frames in flight polls at the top
+ * of each callback (and on a timer) and publishes what has finished, instead of waiting for the pipeline to fill. */
+gm_status gm_poll_frame(gm_ctx *ctx, uint32_t slot);
+
+/* /choppedCloud straight into host memory (the default launch has displayCloud = true: launch/mapping.launch:12,
+ * src/geometric_mapping.cpp:100-107).  xyzw = page-locked memory from gm_host_alloc with room for capacity rows of
+ * 4 floats (x, y, z, pad = input row index), owned by the caller, or NULL to switch the output off for the slot.  Every
+ * later frame of the slot copies its valid cloud there -- the copy starts right behind the NaN-normal compaction, on a
+ * stream of its own, and runs while the rest of the frame (voxel grid, RANSAC, eigen solve) executes -- and is complete
+ * when gm_wait_frame returns; rows [0, n_valid) are the frame's, identical to gm_get_cropped_xyz's.  A frame with more
+ * points than capacity is refused with GM_ERR_CAPACITY at submit. */
+gm_status gm_set_cloud_output(gm_ctx *ctx, uint32_t slot, float *xyzw, uint32_t capacity);
 
 /* Bulky per-frame outputs of a completed slot, fetched only when a display
  * flag needs them (src/geometric_mapping.cpp:100-117).  `capacity` counts
@@ -351,6 +365,9 @@ gm_status gm_group_submit_frame(gm_group *grp, const gm_cloud *cloud);
 /* the oldest frame in flight (submission order); *rank / *slot (may be NULL) name where its bulky outputs can be fetched
  * (gm_get_cropped_xyz(gm_group_ctx(grp, rank), slot, ...)) until that slot is submitted to again */
 gm_status gm_group_wait_frame(gm_group *grp, gm_frame_result *res, uint32_t *rank, uint32_t *slot);
+/* never blocks: GM_OK when the oldest frame in flight has finished (gm_group_wait_frame returns at once),
+ * GM_ERR_NOT_READY while it is running or when no frame is in flight */
+gm_status gm_group_poll_frame(gm_group *grp);
 uint32_t gm_group_in_flight(const gm_group *grp);
 
 #ifdef __cplusplus

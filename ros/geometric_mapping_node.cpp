@@ -32,14 +32,20 @@
 //                          a steady size; a lidar whose point count wanders across 1/16-wide size buckets re-captures
 //                          (hipStreamBeginCapture + hipGraphInstantiate) inside the callback, so it is a choice
 //   gmDevices      string  "0,1,2,...": more than one device streams the frames round-robin over them
-//                          (gm_group_submit_frame / gm_group_wait_frame): the callback submits a frame and publishes the
-//                          oldest finished one once every device is busy -- a pipeline a few frames deep instead of
-//                          the one-frame-at-a-time consumer of src/geometric_mapping.cpp:146,169
+//                          (gm_group_submit_frame / gm_group_poll_frame / gm_group_wait_frame) -- a pipeline a few frames
+//                          deep instead of the one-frame-at-a-time consumer of src/geometric_mapping.cpp:146,169.  Every
+//                          frame is still published, in order, as soon as it has finished: the callback first publishes
+//                          whatever is done (a completion query, no waiting), a 2 ms timer does the same between
+//                          callbacks, and the frames still in flight at shutdown are waited for and published.  A
+//                          frame's header travels with it; a frame that fails is dropped WITH its header.
+// With displayCloud (the launch file's default, launch/mapping.launch:12) /choppedCloud is copied into page-locked host
+// rows while the rest of the frame still runs (gm_set_cloud_output), not fetched afterwards.
 #include <ros/ros.h>
 #include <sensor_msgs/PointCloud2.h>
 #include <sensor_msgs/PointField.h>
 #include <visualization_msgs/MarkerArray.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -131,52 +137,18 @@ visualization_msgs::MarkerArray to_ros(const gm_host::MarkerArray &in)
     return out;
 }
 
-void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input)
+// everything the reference publishes for one frame (src/geometric_mapping.cpp:94-124); the processor's accessors refer
+// to the frame `r` came from
+void publish_frame(const gm_frame_result &r, const std_msgs::Header &header)
 {
-    ROS_INFO("Callback started...");
-    unsigned ox = 0, oy = 4, oz = 8;
-    if (!find_xyz(*input, ox, oy, oz)) { ROS_ERROR("input cloud has no float32 x/y/z fields"); return; }
-    const unsigned n = input->width * input->height;
-    gm_frame_result r;
-    try {
-        // fromROSMsg + chopCloud + getNormals + VoxelGrid + getLocalFrame: one device pass (:55-92)
-        const unsigned char *rows = n ? &input->data[0] : nullptr;
-        std::vector<unsigned char> packed;
-        if (n && input->height > 1 && input->row_step != input->width * input->point_step) {
-            // organised cloud with padded rows: pcl::fromROSMsg honours row_step, the C ABI takes point_step-strided
-            // rows -- drop the padding once on the host
-            packed.resize((size_t)n * input->point_step);
-            for (uint32_t y = 0; y < input->height; ++y)
-                std::memcpy(&packed[(size_t)y * input->width * input->point_step], &input->data[(size_t)y * input->row_step],
-                            (size_t)input->width * input->point_step);
-            rows = &packed[0];
-        }
-        if (params->devices.size() > 1) {
-            // streaming: hand the frame to the next device; publish the oldest frame once the pipeline is full
-            proc->submitFrame(rows, n, input->point_step, ox, oy, oz, input->is_bigendian);
-            headers.push_back(input->header);
-            if (proc->inFlight() < proc->capacity()) return;
-            r = proc->waitFrame();
-        } else {
-            r = proc->processFrame(rows, n, input->point_step, ox, oy, oz, input->is_bigendian);
-            headers.clear();
-            headers.push_back(input->header);
-        }
-    } catch (const gm_host::Error &e) {
-        ROS_ERROR("libgm_hip: %s", e.what());
-        return;
-    }
-    ROS_INFO("Box filter applied...");
-    ROS_INFO("Surface normals found...");
     gm_host::Vector3f vals = {{r.eigenvalues[0], r.eigenvalues[1], r.eigenvalues[2]}};
     gm_host::Matrix3f vecs;
     std::memcpy(vecs.m, r.eigenvectors, sizeof(vecs.m));
     ROS_INFO("Center Axis found...");
-
     if (params->rvizCloud) {  // :100-107, xyz-only PointCloud2 as pcl::toROSMsg lays it out (16-byte points)
-        const gm_host::PointCloud cloud = proc->choppedCloud();
+        const gm_host::PointCloud cloud = proc->choppedCloud();   // (already on the host: enableCloudOutput)
         sensor_msgs::PointCloud2 out;
-        out.header = headers.front();   // (the frame being published: the oldest in flight)
+        out.header = header;
         out.height = 1; out.width = (uint32_t)cloud.size();
         out.is_bigendian = false; out.is_dense = true;
         out.point_step = 16; out.row_step = 16 * out.width;
@@ -198,8 +170,76 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input)
         gm_host::Marker cyl;
         if (gm_host::Processor::rvizCylinder(r, 2.0 * params->boxFilterBound, cyl)) cylinderPub.publish(to_ros(cyl));
     }
-    headers.pop_front();
     ROS_INFO("Published...");
+}
+
+// Streaming: publishes the frames in flight that have finished, oldest first; with `block` every frame in flight.  A frame
+// leaves the queue together with its header whether it succeeded or not (the library has already dropped it).
+void publish_finished(bool block)
+{
+    while (proc && proc->inFlight() && !headers.empty()) {
+        gm_frame_result r;
+        const std_msgs::Header h = headers.front();
+        try {
+            if (block) r = proc->waitFrame();
+            else if (!proc->tryWaitFrame(r)) return;      // the oldest is still running: nothing was taken off the queue
+        } catch (const gm_host::Error &e) {
+            headers.pop_front();
+            ROS_ERROR("libgm_hip: %s", e.what());
+            continue;
+        }
+        headers.pop_front();
+        publish_frame(r, h);
+    }
+}
+
+void timer_cb(const ros::TimerEvent &) { publish_finished(false); }
+
+void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input)
+{
+    ROS_INFO("Callback started...");
+    unsigned ox = 0, oy = 4, oz = 8;
+    if (!find_xyz(*input, ox, oy, oz)) { ROS_ERROR("input cloud has no float32 x/y/z fields"); return; }
+    const unsigned n = input->width * input->height;
+    // fromROSMsg + chopCloud + getNormals + VoxelGrid + getLocalFrame: one device pass (:55-92)
+    const unsigned char *rows = n ? &input->data[0] : nullptr;
+    std::vector<unsigned char> packed;
+    if (n && input->height > 1 && input->row_step != input->width * input->point_step) {
+        // organised cloud with padded rows: pcl::fromROSMsg honours row_step, the C ABI takes point_step-strided
+        // rows -- drop the padding once on the host
+        packed.resize((size_t)n * input->point_step);
+        for (uint32_t y = 0; y < input->height; ++y)
+            std::memcpy(&packed[(size_t)y * input->width * input->point_step], &input->data[(size_t)y * input->row_step],
+                        (size_t)input->width * input->point_step);
+        rows = &packed[0];
+    }
+    if (params->devices.size() > 1) {
+        // streaming: publish what has finished, make room if every slot is taken, hand the frame to the next device
+        publish_finished(false);
+        try {
+            if (proc->inFlight() >= proc->capacity() && !headers.empty()) {
+                const std_msgs::Header h = headers.front();
+                headers.pop_front();                       // (waitFrame takes the frame off the queue, also when it throws)
+                const gm_frame_result r = proc->waitFrame();
+                publish_frame(r, h);
+            }
+            proc->submitFrame(rows, n, input->point_step, ox, oy, oz, input->is_bigendian);
+            headers.push_back(input->header);
+        } catch (const gm_host::Error &e) {
+            ROS_ERROR("libgm_hip: %s", e.what());
+        }
+        return;
+    }
+    gm_frame_result r;
+    try {
+        r = proc->processFrame(rows, n, input->point_step, ox, oy, oz, input->is_bigendian);
+    } catch (const gm_host::Error &e) {
+        ROS_ERROR("libgm_hip: %s", e.what());
+        return;
+    }
+    ROS_INFO("Box filter applied...");
+    ROS_INFO("Surface normals found...");
+    publish_frame(r, input->header);
 }
 
 }  // namespace
@@ -224,12 +264,19 @@ int main(int argc, char **argv)
         ROS_FATAL("libgm_hip: %s", e.what());
         return 1;
     }
+    if (params->rvizCloud) {
+        try { proc->enableCloudOutput(1u << 20); }   // grown by the first larger frame
+        catch (const gm_host::Error &e) { ROS_WARN("libgm_hip: %s (the cloud is fetched after the frame instead)", e.what()); }
+    }
     ros::Subscriber sub = node.subscribe("input", 1, cloud_cb);
+    ros::Timer timer;
+    if (params->devices.size() > 1) timer = node.createTimer(ros::Duration(0.002), timer_cb);
     if (params->rvizCloud) cloudPub = node.advertise<sensor_msgs::PointCloud2>("cloudOutput", 10);
     if (params->rvizNormals) normalsPub = node.advertise<visualization_msgs::MarkerArray>("normalsOutput", 10);
     if (params->rvizCenterAxis) centerAxisPub = node.advertise<visualization_msgs::MarkerArray>("eigenBasisOutput", 10);
     if (params->rvizCylinder) cylinderPub = node.advertise<visualization_msgs::Marker>("centerAxisOutput", 10);  // :165
     ros::spin();
+    publish_finished(true);   // the frames still in flight at shutdown
     proc.reset();
     return 0;
 }

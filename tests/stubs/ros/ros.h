@@ -11,12 +11,16 @@ public:
     template <class M> void publish(const M &) const {}
 };
 class Subscriber {};
+struct Duration { explicit Duration(double) {} };
+struct TimerEvent {};
+class Timer {};
 class NodeHandle {
 public:
     bool getParam(const std::string &, double &) const { return false; }
     bool getParam(const std::string &, bool &) const { return false; }
     bool getParam(const std::string &, std::string &) const { return false; }
     template <class M> Publisher advertise(const std::string &, uint32_t) { return Publisher(); }
+    Timer createTimer(Duration, void (*)(const TimerEvent &)) { return Timer(); }
     template <class M> Subscriber subscribe(const std::string &, uint32_t, void (*)(const gm_stub::shared_ptr<M const> &)) { return Subscriber(); }
 };
 inline void init(int &, char **, const std::string &) {}

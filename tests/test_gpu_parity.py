@@ -645,3 +645,33 @@ def test_graph_replay_is_bitwise_the_enqueued_frame(gm, ransac):
                 assert np.array_equal(va, vb) and np.array_equal(na, nb)
                 if nearest:
                     assert np.array_equal(a.voxel_normals(), b.voxel_normals(), equal_nan=True)
+
+
+def test_poll_frame_and_cloud_output(gm):
+    """gm_poll_frame never blocks and turns true once a submitted frame has finished; gm_set_cloud_output delivers
+    /choppedCloud into caller-owned page-locked rows during the frame -- bytes identical to gm_get_cropped_xyz -- for
+    blocking calls, submitted frames, and frames replayed from a graph."""
+    from geometric_mapping_amd import _lib
+    xyz = [synth.tunnel_frame(50000 + 3000 * s, seed=60 + s, outlier_frac=0.01) for s in range(3)]
+    for flags in (_lib.GM_CFG_DEFAULT | _lib.GM_CFG_RANSAC_CYLINDER, _lib.GM_CFG_DEFAULT | _lib.GM_CFG_GRAPH):
+        with gm.GeometricMapping(n_slots=2, neighborRadius=0.3, flags=flags) as c:
+            assert c.poll_frame(0) is False and c.poll_frame(1) is False      # no frame submitted
+            bufs = [c.cloud_output(s, 70000) for s in range(2)]
+            for k, x in enumerate(xyz):
+                slot = k % 2
+                c.submit_frame(slot, x)
+                spins = 0
+                while not c.poll_frame(slot):
+                    spins += 1
+                    assert spins < 50_000_000
+                r = c.wait_frame(slot)
+                assert c.poll_frame(slot) is True                              # stays true until the slot is submitted to again
+                cloud, rows = c.cropped_cloud(slot)
+                n = r["n_valid"]
+                assert n == len(cloud) > 0
+                assert np.array_equal(bufs[slot][:n, :3], cloud)
+                assert np.array_equal(bufs[slot][:n, 3].copy().view(np.int32), rows)
+            r = c.process_frame(xyz[0])                                        # blocking calls use slot 0
+            assert np.array_equal(bufs[0][:r["n_valid"], :3], c.cropped_cloud(0)[0])
+            with pytest.raises(gm.GmError):                                    # more points than the buffer has rows
+                c.process_frame(synth.tunnel_frame(80000, seed=1))

@@ -181,3 +181,60 @@ def test_group_failure_leaves_no_stale_frame(gm):
             g.voxel_centroids()
         again = g.process_frame(xyz)
         assert again["n_valid"] == ok["n_valid"] and np.array_equal(again["scatter6"], ok["scatter6"])
+
+
+@pytest.mark.gpu
+def test_group_poll_driven_drain_returns_every_frame_in_order(gm):
+    """The node's publish loop (ros/geometric_mapping_node.cpp): frames leave the pipeline through the completion query
+    gm_group_poll_frame -- before each submit and then until nothing is in flight -- never by waiting for the pipeline to
+    fill.  All 100 frames come back, in submission order, each the blocking frame bit for bit; the query never blocks and
+    answers "not ready" on an empty pipeline."""
+    from geometric_mapping_amd import _lib
+    kw = dict(neighborRadius=0.3, flags=_lib.GM_CFG_DEFAULT)
+    frames = [synth.tunnel_frame(20000 + 700 * (i % 5), seed=300 + i, outlier_frac=0.01) for i in range(100)]
+    with gm.GeometricMapping(**kw) as c:
+        ref = []
+        for x in frames:
+            r = c.process_frame(x)
+            ref.append((r["n_in"], r["n_valid"], r["scatter6"].copy(), c.cropped_cloud()[0][:40].copy()))
+    got = []
+    with gm.GeometricMappingGroup([0, 0], loopback=True, n_slots=2, **kw) as g:
+        assert g.poll_frame() is False                       # nothing in flight
+        i = polls = 0
+        while len(got) < len(frames):
+            while g.poll_frame():                            # publish what has finished
+                r, rank, slot = g.wait_frame()
+                got.append((r, g.rank_fetch(rank, slot, "cropped_xyz")[:40, :3].copy()))
+            if i < len(frames) and g.in_flight() < 4:
+                g.submit_frame(frames[i]); i += 1
+            polls += 1
+            assert polls < 50_000_000
+        assert g.in_flight() == 0 and g.poll_frame() is False
+    for k, ((r, head), x) in enumerate(zip(got, ref)):
+        assert r["n_in"] == x[0] and r["n_valid"] == x[1] and np.array_equal(r["scatter6"], x[2]) and np.array_equal(head, x[3]), k
+
+
+@pytest.mark.gpu
+def test_streaming_after_a_sharded_frame_sees_whole_frames_again(gm):
+    """A sharded frame leaves every rank with a slab range -- rank 0 with (-inf, edge[1]).  Frames streamed afterwards are
+    whole frames: every rank must own all of x again, whichever rank the first streamed frame lands on (an odd number of
+    streamed frames before the sharded one makes it rank 1)."""
+    from geometric_mapping_amd import _lib
+    kw = dict(neighborRadius=0.3, flags=_lib.GM_CFG_DEFAULT)
+    frames = [synth.tunnel_frame(30000, seed=400 + i, outlier_frac=0.01) for i in range(6)]
+    with gm.GeometricMapping(**kw) as c:
+        ref = [c.process_frame(x) for x in frames]
+    with gm.GeometricMappingGroup([0, 0], loopback=True, n_slots=1, **kw) as g:
+        g.submit_frame(frames[0])                            # lands on rank 0; the next streamed frame goes to rank 1
+        r0, rank0, _ = g.wait_frame()
+        assert rank0 == 0 and r0["n_valid"] == ref[0]["n_valid"]
+        sh = g.process_frame(frames[1])                      # sharded: ranks now own slabs
+        assert sh["n_valid"] == ref[1]["n_valid"]
+        seen = []
+        for k in range(2, 6):
+            g.submit_frame(frames[k])
+            r, rank, _ = g.wait_frame()
+            seen.append(rank)
+            assert r["n_valid"] == ref[k]["n_valid"] and r["n_cropped"] == ref[k]["n_cropped"], (k, rank)
+            assert np.array_equal(r["scatter6"], ref[k]["scatter6"]), (k, rank)
+        assert set(seen) == {0, 1}
