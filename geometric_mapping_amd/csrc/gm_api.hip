@@ -76,8 +76,14 @@ static int rows_per_radius(double radius, float ex, float ey, float ez, uint32_t
     if (!(vol > 0.0) || n_points == 0) return 1;
     const double k_est = 10.0 * (double)n_points * (4.18879 * radius * radius * radius) / vol;
     // measured on the 1 M-point tunnel frame (tools/sweep_rows.sh): r = 0.25 (estimate 650, true k 1 280): D = 1 / 2 / 3 / 4
-    // = 0.446 / 0.422 / 0.477 / 0.536 ms; r = 0.5 (estimate 5 200, true k 5 100): 1.47 / 1.24 / 1.25 / 1.21 ms
-    return k_est < 400.0 ? 1 : (k_est < 2000.0 ? 2 : 4);
+    // = 0.446 / 0.422 / 0.477 / 0.536 ms; r = 0.5 (estimate 5 200, true k 5 100): 1.47 / 1.24 / 1.25 / 1.21 ms.
+    // Round 4, on a lidar-shaped frame (synth.velodyne_tunnel, 64 rings x 1 800, r = 0.5: estimate 600, k from ~100 to 7 600
+    // along a row, median 2 350; tools/lidar_probe.py): D = 1 / 2 / 3 / 4 = 0.213 / 0.242 / 0.240 / 0.279 ms -- the estimate
+    // is weighted by points (dense patches beside the sensor), a tile's length by rows, and most rows of such a frame are
+    // thin: their 64-point tiles are several radii long, where finer rows only lengthen the candidate stream.  The band
+    // in which D = 2 was chosen (estimate 400 .. 2 000) bought 5 % on the uniform tunnel and cost 13 % on the lidar frame --
+    // the reference's actual input (launch/mapping.launch:22) -- so it is gone: D = 1 below 2 000, D = 4 from there.
+    return k_est < 2000.0 ? 1 : 4;
 }
 
 GridParams make_grid(float lo_x, float lo_y, float lo_z, float ex, float ey, float ez, double radius, uint32_t n_points)
@@ -793,13 +799,13 @@ gm_status gm_create(const gm_config *cfg, gm_ctx **out)
         if (!ctx->slots) return GM_ERR_OOM;
         for (uint32_t i = 0; i < ctx->n_slots; ++i) {
             Slot &sl = ctx->slots[i];
+            sl.pipelined = ctx->n_slots > 1;
             GM_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
             for (int k = 0; k <= GM_N_STAGES; ++k) GM_HIP(ctx, hipEventCreate(&sl.ev[k]));
             GM_HIP(ctx, hipEventCreate(&sl.ev_k0));
             GM_HIP(ctx, hipEventCreate(&sl.ev_k1));
-            GM_HIP(ctx, hipStreamCreateWithFlags(&sl.copy_stream, hipStreamNonBlocking));
-            GM_HIP(ctx, hipEventCreateWithFlags(&sl.ev_valid, hipEventDisableTiming));
-            GM_HIP(ctx, hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming));
+            // (the /choppedCloud copy stream is created by gm_set_cloud_output: every stream of the process takes part in
+            // the runtime's mapping of streams onto hardware queues, and an idle one can push two slots onto one queue)
             GM_HIP(ctx, dmalloc(sl.ctr, 1));
             GM_HIP(ctx, dmalloc(sl.voxp, 1));
             GM_HIP(ctx, dmalloc(sl.d_out, 1));
@@ -923,6 +929,11 @@ gm_status gm_set_cloud_output(gm_ctx *ctx, uint32_t slot, float *xyzw, uint32_t 
             (void)hipGetLastError();
             return fail(ctx, GM_ERR_INVALID_ARG, "gm_set_cloud_output: the buffer must be page-locked memory from gm_host_alloc");
         }
+    }
+    if (xyzw && !sl.copy_stream) {
+        GM_HIP(ctx, hipStreamCreateWithFlags(&sl.copy_stream, hipStreamNonBlocking));
+        GM_HIP(ctx, hipEventCreateWithFlags(&sl.ev_valid, hipEventDisableTiming));
+        GM_HIP(ctx, hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming));
     }
     sl.cloud_out = reinterpret_cast<float4 *>(xyzw);
     sl.cloud_out_cap = xyzw ? capacity : 0u;

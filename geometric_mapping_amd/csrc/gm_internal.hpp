@@ -103,6 +103,7 @@ struct Slot {
     hipEvent_t ev_valid = nullptr, ev_copied = nullptr;
     // state
     bool submitted = false, complete = false;
+    bool pipelined = false;      // the context keeps several frames in flight (n_slots > 1): kernels choose block shapes that share the chip
     bool vox_sort_path = false;  // this frame's voxels came from the sort path (may report passthrough)
     uint32_t n_in = 0;
     gm_frame_result last = {};

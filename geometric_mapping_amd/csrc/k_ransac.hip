@@ -985,8 +985,10 @@ bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels
     static const char *fs = getenv("GM_RANSAC_FINAL");   // "sel": the last stage in the lane <-> hypothesis shape (A/B timing)
     if (masks && K2 <= (uint32_t)kStK && !(fs && fs[0] == 's')) {
         // the last stage streams: lane <-> point, hypotheses in scalar registers (k_score_stream); also leaves the inlier masks
+        // (every block ends with one atomic per hypothesis on the same K words, ~12 ns each and one after the other: 814
+        // blocks of 1024 points made the 1 M-point launch 16.7 us.  A block per CU walks its share of the points instead.)
         uint32_t nb = (n_cap + kStThreads * kStPer - 1) / (kStThreads * kStPer);
-        if (nb > 8192u) nb = 8192u;
+        if (nb > 256u) nb = 256u;
         if (nb == 0) nb = 1;
         if (model == 0)
             hipLaunchKernelGGL(k_score_stream<0>, dim3(nb), dim3(kStThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8, cb,

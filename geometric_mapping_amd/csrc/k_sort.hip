@@ -26,19 +26,21 @@
 // Round 3 ran two launches per pass (per-block histogram rows, then a scatter whose blocks summed the rows of the blocks
 // before them: 204 thin blocks, up to 25 dependent L2 round trips for the last one) and three 11-bit passes + a gather
 // launch: 3 x (6.6 + 19.5) + 28.5 us on the 1 M-point frame.  See DESIGN.md par. 4 for what this one measures.
+#include <stdlib.h>
+
 #include "gm_internal.hpp"
 
 namespace gm {
 
-constexpr int kRsThreads = 1024;
-constexpr int kRsWaves = kRsThreads / kWave;      // 16
+// Block shape: 1024 threads (tile 8192, 115 KB of LDS) or 512 (tile 4096, 60 KB).  The large one is the faster pass when a
+// frame runs alone (half the tiles: every tile's look-back fits one window); the small one slots in beside the blocks of
+// other frames' kernels (k_normals: 256 threads, 40 KB) when several frames are in flight -- launch_radix_sort chooses.
 constexpr int kRsItems = 8;                       // keys a lane holds
-constexpr int kRsTile = kRsThreads * kRsItems;    // 8192 positions per tile
+constexpr int kRsMinTile = 512 * kRsItems;        // the record arrays are laid out for the small tile
 constexpr int kRsMaxBits = 9;                     // two threads per digit (the halves of the look-back)
 constexpr int kRsMaxPasses = 4;
 constexpr int kRsTotalsStride = 2048;             // words per pass in the totals array (gm_api.hip zero-fills them)
-constexpr int kRsWindowLoads512 = 7;               // 16-byte record loads a thread holds in flight (9-bit digits: 16 tiles per load round)
-constexpr int kRsWindowLoads256 = 4;               // ... (8-bit digits: 32 tiles per load round)
+constexpr int kRsWindow = 112;                    // tiles (at least) whose 16-bit rows a block sums directly; one load round covers threads / (bins / 8) tiles
 
 #ifdef GM_SORT_TIMELINE   // diagnostic builds (tools/sort_timeline.py): 100 MHz ticks of every block's phases, [pass][tile][8]
 __device__ unsigned long long gm_sort_tl[4][256][8];
@@ -58,7 +60,7 @@ SortPlan radix_plan(int key_bits)
     return p;
 }
 
-uint32_t radix_tiles(uint32_t n_cap) { return (n_cap + kRsTile - 1) / kRsTile; }
+uint32_t radix_tiles(uint32_t n_cap, uint32_t tile = kRsMinTile) { return (n_cap + tile - 1) / tile; }
 // record words of one pass: per tile a row of 16-bit counts and a row of 32-bit inclusive prefixes
 static size_t radix_pass_words(uint32_t n_cap, int bits) { return (size_t)radix_tiles(n_cap) * ((size_t)1 << bits) * 3 / 2; }
 
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(1024) void k_rs_hist_all(const uint32_t *__restrict
 //      taking 16 tiles per load round -- the 101 tiles before the last one of a 1 M-point frame are 101 KB, one trip.
 //      Sorts of more than 112 tiles add, per tile, a row of 32-bit INCLUSIVE prefixes: a tile sums the 16-bit rows of the
 //      112 tiles before it and the inclusive row of the tile before those.  All records are cleared when the frame opens.
-template <int BITS, bool GATHER>
+template <int BITS, bool GATHER, int kRsThreads>
 __global__ __launch_bounds__(kRsThreads) void k_rs_pass(const uint32_t *__restrict__ keys_in,
                                                         const uint32_t *__restrict__ vals_in,
                                                         uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
@@ -138,14 +140,16 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_pass(const uint32_t *__restri
                                                         const float4 *__restrict__ rows_in, float4 *__restrict__ rows_out)
 {
     constexpr int BINS = 1 << BITS;
-    static_assert(BITS == 8 || BITS == 9, "8 digits per 16-byte record load, 16 or 32 tiles per load round");
+    constexpr int kRsWaves = kRsThreads / kWave, kRsTile = kRsThreads * kRsItems;
+    static_assert(BITS == 8 || BITS == 9, "8 digits per 16-byte record load");
+    static_assert(BINS <= kRsThreads, "a thread per digit");
     __shared__ uint32_t cw[kRsWaves][BINS];            // per wave: digit count of the tile, then its next local slot
     // the tile in digit order (keys, then values); before that, the lane masks of the ranking: [wave][digit] 64-bit
     __shared__ __attribute__((aligned(16))) uint32_t stage[2 * kRsTile];
     static_assert(sizeof(unsigned long long) * kRsWaves * BINS <= sizeof(uint32_t) * 2 * kRsTile, "lane masks fit the staging image");
     __shared__ uint32_t lstart[BINS], gpos[BINS];      // per digit: first slot in the image / in the output
-    constexpr int OCTS = BINS / 8, GROUPS = kRsThreads / OCTS, LOADS = BITS == 9 ? kRsWindowLoads512 : kRsWindowLoads256;
-    constexpr uint32_t WINDOW = GROUPS * LOADS;        // tiles whose 16-bit rows a block sums directly
+    constexpr int OCTS = BINS / 8, GROUPS = kRsThreads / OCTS, LOADS = (kRsWindow + GROUPS - 1) / GROUPS;   // (16-byte record loads a thread holds in flight)
+    constexpr uint32_t WINDOW = GROUPS * LOADS;        // tiles whose 16-bit rows a block sums directly (112 or 128)
     __shared__ __attribute__((aligned(16))) uint32_t lbq[GROUPS][OCTS][4];   // look-back: the groups' packed partial sums; also the rows being published
     __shared__ uint32_t wsum_b[kRsWaves], wsum_t[kRsWaves];
     __shared__ uint32_t s_tile, s_more;
@@ -364,17 +368,17 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_pass(const uint32_t *__restri
 #endif
 }
 
-template <int BITS>
+template <int BITS, int THREADS>
 static void rs_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, const uint32_t *n_ptr,
                     int shift, uint32_t nb, const uint32_t *totals, uint32_t *rec, uint32_t *ticket,
                     const float4 *rows_in, float4 *rows_out, hipStream_t s)
 {
     if (rows_out)
-        hipLaunchKernelGGL((k_rs_pass<BITS, true>), dim3(nb), dim3(kRsThreads), 0, s, kin, vin, kout, vout, n_ptr, shift, totals, rec,
-                           ticket, rows_in, rows_out);
+        hipLaunchKernelGGL((k_rs_pass<BITS, true, THREADS>), dim3(nb), dim3(THREADS), 0, s, kin, vin, kout, vout, n_ptr, shift, totals,
+                           rec, ticket, rows_in, rows_out);
     else
-        hipLaunchKernelGGL((k_rs_pass<BITS, false>), dim3(nb), dim3(kRsThreads), 0, s, kin, vin, kout, vout, n_ptr, shift, totals, rec,
-                           ticket, rows_in, rows_out);
+        hipLaunchKernelGGL((k_rs_pass<BITS, false, THREADS>), dim3(nb), dim3(THREADS), 0, s, kin, vin, kout, vout, n_ptr, shift, totals,
+                           rec, ticket, rows_in, rows_out);
 }
 
 // Sorts (keys_a, index) by the low key_bits bits of the keys.  Returns 0 if the sorted keys (and values) end in
@@ -386,9 +390,12 @@ int launch_radix_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint
                       uint32_t n_cap, int key_bits, Slot &sl, bool prepared, hipStream_t s, const float4 *rows_in,
                       float4 *rows_out)
 {
-    const uint32_t nb = radix_tiles(n_cap);
-    if (nb == 0) return 0;
+    if (n_cap == 0) return 0;
     const SortPlan plan = radix_plan(key_bits);
+    // block shape (see the top of the file).  GM_SORT_THREADS=512|1024: experiments
+    static const char *te = getenv("GM_SORT_THREADS");
+    const int threads = te ? (atoi(te) >= 1024 ? 1024 : 512) : (sl.pipelined ? 512 : 1024);
+    const uint32_t nb = radix_tiles(n_cap, (uint32_t)threads * kRsItems);
     uint32_t *totals = sl.sort.totals;
     if (!prepared) {
         (void)hipMemsetAsync(totals, 0, radix_totals_bytes(), s);
@@ -406,9 +413,12 @@ int launch_radix_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint
         const bool last = p + 1 == plan.passes;
         const float4 *ri = last ? rows_in : nullptr;
         float4 *ro = last ? rows_out : nullptr;
-        switch (plan.bits) {
-        case 8: rs_pass<8>(kin, vin, kout, vout, n_ptr, shift, nb, tot, rec, sl.sort.ticket, ri, ro, s); break;
-        default: rs_pass<9>(kin, vin, kout, vout, n_ptr, shift, nb, tot, rec, sl.sort.ticket, ri, ro, s); break;
+        if (threads == 1024) {
+            if (plan.bits == 8) rs_pass<8, 1024>(kin, vin, kout, vout, n_ptr, shift, nb, tot, rec, sl.sort.ticket, ri, ro, s);
+            else rs_pass<9, 1024>(kin, vin, kout, vout, n_ptr, shift, nb, tot, rec, sl.sort.ticket, ri, ro, s);
+        } else {
+            if (plan.bits == 8) rs_pass<8, 512>(kin, vin, kout, vout, n_ptr, shift, nb, tot, rec, sl.sort.ticket, ri, ro, s);
+            else rs_pass<9, 512>(kin, vin, kout, vout, n_ptr, shift, nb, tot, rec, sl.sort.ticket, ri, ro, s);
         }
         if (p == 0) { kin = keys_b; vin = vals_b; kout = keys_a; vout = vals_a; }
         else {

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["tunnel_frame", "cylinder_frame", "plane_patch", "fixed_k_radius", "to_pointcloud2"]
+__all__ = ["tunnel_frame", "cylinder_frame", "plane_patch", "fixed_k_radius", "to_pointcloud2", "velodyne_tunnel", "drop_row_padding"]
 
 
 def _basis(axis):
@@ -84,3 +84,63 @@ def to_pointcloud2(xyz, point_step=16, offsets=(0, 4, 8), fill=0):
     for k, off in enumerate(offsets):
         buf[:, off:off + 4] = raw[:, 4 * k:4 * k + 4]
     return buf.reshape(-1)
+
+
+def velodyne_tunnel(rings=16, az=1800, seed=0, radius=2.0, axis_offset=(0.3, 0.5), floor_z=-1.2, sigma=0.01,
+                    max_range=30.0, nan_frac=0.02, point_step=32, row_pad=0):
+    """A spinning multi-beam lidar inside the tunnel: what /velodyne_points carries
+    (/root/reference launch/mapping.launch:22; the reference's only data hint is a Velodyne rosbag, :29-32).
+
+    The sensor sits at the origin; the tunnel is a cylinder of `radius` around an x-parallel axis through
+    (0, axis_offset), cut by a floor plane z = floor_z.  `rings` beams at evenly spaced elevations (+-15 deg for 16 rings,
+    -25..+15 deg otherwise, like the VLP-16 / HDL-32 / HDL-64) sweep `az` azimuth steps; every ray returns its nearest hit
+    with N(0, sigma) range noise, or NaN when it hits nothing within max_range (rays along the tunnel) or drops out
+    (nan_frac).  The cloud is ORGANISED: height = rings, width = az, one row of the message per ring, each row
+    row_pad bytes longer than width * point_step -- row_step padding, which pcl::fromROSMsg honours
+    (src/geometric_mapping.cpp:55).  Density falls off with range: a few centimetres between returns on the wall beside
+    the sensor, decimetres at the far ends of the crop box -- the frame the uniform-density generator above is not.
+
+    Returns dict(data=uint8 message bytes, height, width, point_step, row_step, offsets=(x, y, z),
+                 xyz=float32 [height * width, 3] in message order, NaN rows included).
+    point_step 32: x, y, z at 0 / 4 / 8, intensity float at 16, ring uint16 at 20 (velodyne_pointcloud's XYZIR);
+    point_step 22: x, y, z at 0 / 4 / 8, intensity at 12, ring at 16, time float at 18 (XYZIRT, unaligned rows)."""
+    if point_step not in (22, 32):
+        raise ValueError("point_step must be 22 or 32")
+    rng = np.random.default_rng(seed)
+    el = np.deg2rad(np.linspace(-15.0, 15.0, rings) if rings <= 16 else np.linspace(-25.0, 15.0, rings))
+    th = np.linspace(0.0, 2.0 * np.pi, az, endpoint=False) + rng.uniform(0, 2 * np.pi / az)
+    E, T = np.meshgrid(el, th, indexing="ij")                  # [rings, az]
+    d = np.stack([np.cos(E) * np.cos(T), np.cos(E) * np.sin(T), np.sin(E)], axis=-1).reshape(-1, 3)
+    oy, oz = float(axis_offset[0]), float(axis_offset[1])
+    # cylinder around the x-parallel axis through (0, oy, oz): |(t d)_yz - (oy, oz)|^2 = R^2, sensor inside
+    a = d[:, 1] ** 2 + d[:, 2] ** 2
+    b = -2.0 * (d[:, 1] * oy + d[:, 2] * oz)
+    c = oy * oy + oz * oz - radius * radius
+    disc = b * b - 4.0 * a * c
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t_cyl = np.where(a > 1e-12, (-b + np.sqrt(np.maximum(disc, 0.0))) / (2.0 * a), np.inf)
+        t_floor = np.where(d[:, 2] < -1e-9, floor_z / d[:, 2], np.inf) if floor_z is not None else np.full(len(d), np.inf)
+    t = np.minimum(t_cyl, t_floor)
+    t = t + rng.normal(0.0, sigma, len(t))
+    hit = np.isfinite(t) & (t > 0.3) & (t < max_range) & (rng.random(len(t)) >= nan_frac)
+    xyz = np.where(hit[:, None], d * t[:, None], np.nan).astype(np.float32)
+    row_step = az * point_step + int(row_pad)
+    buf = np.full((rings, row_step), 0xC3, dtype=np.uint8)
+    pts = buf[:, : az * point_step].reshape(rings, az, point_step)
+    raw = xyz.view(np.uint8).reshape(rings, az, 12)
+    pts[:, :, 0:12] = raw
+    inten = rng.uniform(0, 255, rings * az).astype(np.float32).view(np.uint8).reshape(rings, az, 4)
+    ring = np.repeat(np.arange(rings, dtype=np.uint16), az).view(np.uint8).reshape(rings, az, 2)
+    if point_step == 32:
+        pts[:, :, 16:20] = inten; pts[:, :, 20:22] = ring
+    else:
+        pts[:, :, 12:16] = inten; pts[:, :, 16:18] = ring
+    return dict(data=np.ascontiguousarray(buf).reshape(-1), height=rings, width=az, point_step=point_step, row_step=row_step,
+                offsets=(0, 4, 8), xyz=xyz)
+
+
+def drop_row_padding(msg):
+    """What the node does with an organised cloud whose rows are padded (ros/geometric_mapping_node.cpp): the C ABI takes
+    point_step-strided rows, so the row_step padding is dropped once on the host.  Returns the packed uint8 rows."""
+    h, w, ps, rs = msg["height"], msg["width"], msg["point_step"], msg["row_step"]
+    return np.ascontiguousarray(msg["data"].reshape(h, rs)[:, : w * ps]).reshape(-1)

@@ -28,13 +28,17 @@ CASES = {
     "cylinder_tilted_3k": (dict(n=3000, seed=1, axis=(1, 0.2, -0.1)), 5.0, 0.55, 0.5, 0.2),
     "tunnel_floor_outliers_4k": (dict(n=4000, seed=2, floor_z=-1.2, outlier_frac=0.02), 5.0, 0.5, 0.4, 0.25),
     "small_box_sparse_1k": (dict(n=1000, seed=3, outlier_frac=0.05), 2.5, 0.45, 0.3, 0.1),
+    # a spinning 16-beam lidar inside the tunnel (synth.velodyne_tunnel: organised, NaN returns, density falling off with
+    # range), the launch file's own values (launch/mapping.launch:7-10)
+    "velodyne16_tunnel_7k": (dict(lidar=True, rings=16, az=450, seed=4), 5.0, 0.5, 0.5, 0.2),
 }
 
 
 def main():
     oc.build()
     for name, (gen, b, r, leaf, wf) in CASES.items():
-        xyz = synth.tunnel_frame(**gen)
+        gen = dict(gen)
+        xyz = synth.velodyne_tunnel(**gen)["xyz"] if gen.pop("lidar", False) else synth.tunnel_frame(**gen)
         keep = oc.crop_box(xyz, b)
         c1 = xyz[keep]
         n64, cnt = oc.normals(c1, r, oc.F64)

@@ -675,3 +675,49 @@ def test_poll_frame_and_cloud_output(gm):
             assert np.array_equal(bufs[0][:r["n_valid"], :3], c.cropped_cloud(0)[0])
             with pytest.raises(gm.GmError):                                    # more points than the buffer has rows
                 c.process_frame(synth.tunnel_frame(80000, seed=1))
+
+
+@pytest.mark.parametrize("rings,az,step,pad", [(16, 900, 32, 24), (32, 600, 22, 10)])
+def test_lidar_shaped_organised_cloud_matches_oracle(gm, oc, rings, az, step, pad):
+    """What /velodyne_points carries (launch/mapping.launch:22): an ORGANISED height x width cloud of a spinning multi-beam
+    lidar inside the tunnel -- rows of the message padded (row_step), 32-byte XYZIR or unaligned 22-byte XYZIRT points, NaN
+    returns, the sensor at the origin, density falling off with range (neighbour counts from a dozen to thousands at the
+    launch file's neighborRadius = 0.5) -- through the frame path with the launch file's values.  Crop, neighbour sets,
+    NaN-normal removal and voxels exact; normals, scatter matrix and axis to north_star's 1e-5 where well-posed."""
+    from geometric_mapping_amd import _lib
+    msg = synth.velodyne_tunnel(rings=rings, az=az, seed=9, point_step=step, row_pad=pad)
+    xyz = msg["xyz"]
+    rows = synth.drop_row_padding(msg)          # (what the node does with padded rows)
+    assert msg["row_step"] == az * step + pad and np.isnan(xyz[:, 0]).sum() > 0
+    bound, radius, leaf, wf = 5.0, 0.5, 0.5, 0.2
+    with gm.GeometricMapping(boxFilterBound=bound, voxelGridLeafSize=leaf, neighborRadius=radius, weightingFactor=wf,
+                             flags=_lib.GM_CFG_DEFAULT | _lib.GM_CFG_KEEP_COUNTS) as c:
+        res = c.process_frame(c.cloud_from_rows(rows, len(xyz), step, msg["offsets"]))
+        cloud, crows = c.cropped_cloud()
+        nrm = c.normals()
+        cnt = c.neighbor_counts()
+        cen, vcnt = c.voxel_centroids()
+    keep = oc.crop_box(xyz, bound)
+    o_n, o_cnt = oc.normals(xyz[keep], radius, oc.F64)
+    assert res["n_in"] == rings * az and res["n_cropped"] == len(keep)
+    assert np.array_equal(cnt, o_cnt) and o_cnt.max() > 20 * max(int(o_cnt.min()), 1)     # density really varies
+    valid = oc.finite_normals(o_n)
+    o = oc.process_frame(xyz, bound, radius, leaf, wf, oc.F64)
+    assert np.array_equal(crows, keep[valid]) and np.array_equal(cloud, xyz[keep][valid])
+    assert res["n_valid"] == o["n_valid"] and res["n_voxels"] == o["n_voxels"]
+    assert np.abs(cen - o["voxels"]).max() < 2e-6 * bound
+    # normals: a neighbourhood that is one ring's arc is a line, its plane is rounding noise in any precision -- the bound
+    # is north_star's 1e-5 or half of what the reference's own fp32 arithmetic deviates from the f64 value, as in the fuzz
+    s = np.linalg.norm(np.cross(nrm[:, :3].astype(np.float64), o["normals"][:, :3].astype(np.float64)), axis=1)
+    a = np.arcsin(np.clip(s, 0, 1))
+    o32 = oc.normals(xyz[keep], radius, oc.F32_FAITHFUL)[0][valid]
+    fin = np.isfinite(o32[:, 0])
+    s32 = np.linalg.norm(np.cross(o32[fin, :3].astype(np.float64), o["normals"][fin, :3].astype(np.float64)), axis=1)
+    ref_dev = float(np.quantile(np.arcsin(np.clip(s32, 0, 1)), 0.98))
+    assert np.quantile(a, 0.98) < max(1e-5, 0.5 * ref_dev), (np.quantile(a, 0.98), ref_dev)
+    M = o["M"]
+    assert np.abs(res["scatter"] - M).max() / np.abs(M).max() < 1e-5
+    ev = o["evals"].astype(np.float64)
+    assert abs(res["eigenvalues"][2] - ev[2]) / ev[2] < 1e-5 and abs(res["eigenvalues"][1] - ev[1]) / ev[1] < 1e-5
+    ax, oax = res["center_axis"].astype(np.float64), o["evecs"][:, 0].astype(np.float64)
+    assert np.linalg.norm(np.cross(ax, oax)) / (np.linalg.norm(ax) * np.linalg.norm(oax)) < 1e-5
