@@ -135,6 +135,8 @@ def load():
         "gm_default_config": (None, [cfgp]),
         "gm_host_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
         "gm_host_free": (C.c_int, [vp, vp]),
+        "gm_host_register": (C.c_int, [vp, vp, C.c_size_t]),
+        "gm_host_unregister": (C.c_int, [vp, vp]),
         "gm_abi_version": (u32, []),
         "gm_status_string": (C.c_char_p, [C.c_int]),
         "gm_last_error": (C.c_char_p, [vp]),

@@ -63,6 +63,9 @@ class GeometricMapping:
             for slot in getattr(self, "_cloud_slots", []):   # (waits for a frame that still writes the buffer)
                 self._L.gm_set_cloud_output(self._ctx, slot, None, 0)
             self._cloud_slots = []
+            for a in getattr(self, "_registered", []):
+                self._L.gm_host_unregister(self._ctx, a.ctypes.data)
+            self._registered = []
             for p in getattr(self, "_pinned", []):
                 self._L.gm_host_free(self._ctx, p)
             self._pinned = []
@@ -168,6 +171,20 @@ class GeometricMapping:
         if st == GM_ERR_NOT_READY:
             return False
         self._check(st)
+
+    def cloud_output_into(self, slot, array):
+        """The same into memory the caller owns: a C-contiguous float32 [capacity, 4] numpy array (e.g. the buffer a message
+        is published from) is page-locked (gm_host_register) and registered as the slot's /choppedCloud output.  The array
+        must outlive the context (or a cloud_output_into(slot, None))."""
+        if array is None:
+            self._check(self._L.gm_set_cloud_output(self._ctx, slot, None, 0))
+            return None
+        assert array.dtype == np.float32 and array.ndim == 2 and array.shape[1] == 4 and array.flags["C_CONTIGUOUS"]
+        self._check(self._L.gm_host_register(self._ctx, array.ctypes.data, array.nbytes))
+        self._registered = getattr(self, "_registered", []) + [array]
+        self._check(self._L.gm_set_cloud_output(self._ctx, slot, array.ctypes.data_as(C.POINTER(C.c_float)), array.shape[0]))
+        self._cloud_slots = getattr(self, "_cloud_slots", []) + [slot]
+        return array
 
     def cloud_output(self, slot, capacity):
         """Registers a page-locked /choppedCloud buffer for the slot (gm_set_cloud_output): every later frame of the slot

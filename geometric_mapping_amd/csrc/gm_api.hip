@@ -350,6 +350,19 @@ static gm_status enqueue_launches(gm_ctx *ctx, Slot &sl, const RowLayout &rows, 
         launch_zero_fill(z, s);
     }
     launch_crop(rows, n, lo, hi, g, sl, s, ns, n_dev, true);   // (also counts the digit totals of the cell sort)
+    // /choppedCloud to the caller's page-locked rows (gm_set_cloud_output), on a stream of its own, in two steps.  Up to the
+    // first point that loses its normal the valid cloud IS the cropped cloud: the cropped rows leave right here, with
+    // nearly the whole frame still ahead of them to hide the copy behind; what the NaN-normal compaction moved is sent
+    // again below (nothing at all on a dense frame).  The first copy is a DMA of the frame's n rows (>= n_cropped, whose
+    // value only the device knows; a kernel writing the mapped rows with the exact count was measured: 64 blocks of
+    // stores over PCIe take 0.6 ms for 13 MB where the DMA engine takes 0.25); the second is a kernel that reads the
+    // counts on the device and writes the mapped host rows.  (Inside a captured graph: one in-line copy further down.)
+    const bool cloud_overlap = sl.cloud_out && n && !sl.capturing && sl.cloud_out_dev;
+    if (cloud_overlap) {
+        GM_HIP(ctx, hipEventRecord(sl.ev_crop, s));
+        GM_HIP(ctx, hipStreamWaitEvent(sl.copy_stream, sl.ev_crop, 0));
+        GM_HIP(ctx, hipMemcpyAsync(sl.cloud_out, sl.crop4, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, sl.copy_stream));
+    }
     record(ctx, sl, 2);
     launch_grid_and_normals(g, vd, sl, ns, (cf.flags & GM_CFG_KEEP_COUNTS) != 0, true, s);
     record(ctx, sl, 3);  // end of grid+normals; the kernel alone is bracketed by ev_k0/ev_k1
@@ -357,21 +370,16 @@ static gm_status enqueue_launches(gm_ctx *ctx, Slot &sl, const RowLayout &rows, 
     uint32_t row_tile = kCpTile;
     const uint32_t nparts = launch_compact_valid(sl, ns, cf.weightingFactor, s, &row_tile);
     bool cloud_copy_pending = false;
-    if (sl.cloud_out && n) {
-        // /choppedCloud to the caller's page-locked rows: the valid cloud is final here.  The number of valid points is
-        // only known on the device, so the copy takes the frame's n rows (>= n_valid; the host reads the first n_valid).
-        // On its own stream it overlaps everything that follows; inside a captured graph it stays in line.
-        const size_t bytes = (size_t)n * sizeof(float4);
-        if (sl.capturing) {   // (a captured copy's size is frozen: the bucketed size, as far as the buffer has rows -- both >= n)
-            const size_t frozen = (size_t)(ns < sl.cloud_out_cap ? ns : sl.cloud_out_cap) * sizeof(float4);
-            GM_HIP(ctx, hipMemcpyAsync(sl.cloud_out, sl.valid4, frozen, hipMemcpyDeviceToHost, s));
-        } else {
-            GM_HIP(ctx, hipEventRecord(sl.ev_valid, s));
-            GM_HIP(ctx, hipStreamWaitEvent(sl.copy_stream, sl.ev_valid, 0));
-            GM_HIP(ctx, hipMemcpyAsync(sl.cloud_out, sl.valid4, bytes, hipMemcpyDeviceToHost, sl.copy_stream));
-            GM_HIP(ctx, hipEventRecord(sl.ev_copied, sl.copy_stream));
-            cloud_copy_pending = true;
-        }
+    if (cloud_overlap) {
+        GM_HIP(ctx, hipEventRecord(sl.ev_valid, s));
+        GM_HIP(ctx, hipStreamWaitEvent(sl.copy_stream, sl.ev_valid, 0));
+        launch_rows_to_host(sl.valid4, sl.cloud_out_dev, &sl.ctr->first_drop_enc, &sl.ctr->n_valid, sl.copy_stream);
+        GM_HIP(ctx, hipEventRecord(sl.ev_copied, sl.copy_stream));
+        cloud_copy_pending = true;
+    } else if (sl.cloud_out && n) {
+        // (a captured copy's size is frozen: the bucketed size, as far as the buffer has rows -- both >= n_valid)
+        const size_t frozen = (size_t)(ns < sl.cloud_out_cap ? ns : sl.cloud_out_cap) * sizeof(float4);
+        GM_HIP(ctx, hipMemcpyAsync(sl.cloud_out, sl.valid4, frozen, hipMemcpyDeviceToHost, s));
     }
     record(ctx, sl, 4);
     record(ctx, sl, 5);
@@ -722,6 +730,27 @@ gm_status gm_host_free(gm_ctx *ctx, void *ptr)
     return GM_OK;
 }
 
+gm_status gm_host_register(gm_ctx *ctx, void *ptr, size_t bytes)
+{
+    if (!ctx || !ptr || !bytes) return fail(ctx, GM_ERR_INVALID_ARG, "gm_host_register: NULL argument");
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return fail(ctx, GM_ERR_DEVICE, "hipSetDevice failed");
+    if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, GM_ERR_INVALID_ARG, "gm_host_register: hipHostRegister failed (already registered, or not host memory)");
+    }
+    return GM_OK;
+}
+
+gm_status gm_host_unregister(gm_ctx *ctx, void *ptr)
+{
+    if (!ptr) return GM_OK;
+    if (hipHostUnregister(ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, GM_ERR_INVALID_ARG, "gm_host_unregister: not a registered pointer");
+    }
+    return GM_OK;
+}
+
 uint32_t gm_abi_version(void) { return GM_ABI_VERSION; }
 
 
@@ -860,6 +889,7 @@ void gm_destroy(gm_ctx *ctx)
             if (sl.ev_k0) hipEventDestroy(sl.ev_k0);
             if (sl.ev_k1) hipEventDestroy(sl.ev_k1);
             if (sl.copy_stream) { hipStreamSynchronize(sl.copy_stream); hipStreamDestroy(sl.copy_stream); }
+            if (sl.ev_crop) hipEventDestroy(sl.ev_crop);
             if (sl.ev_valid) hipEventDestroy(sl.ev_valid);
             if (sl.ev_copied) hipEventDestroy(sl.ev_copied);
             if (sl.stream) hipStreamDestroy(sl.stream);
@@ -927,13 +957,20 @@ gm_status gm_set_cloud_output(gm_ctx *ctx, uint32_t slot, float *xyzw, uint32_t 
         hipPointerAttribute_t a;
         if (hipPointerGetAttributes(&a, xyzw) != hipSuccess || a.type != hipMemoryTypeHost) {
             (void)hipGetLastError();
-            return fail(ctx, GM_ERR_INVALID_ARG, "gm_set_cloud_output: the buffer must be page-locked memory from gm_host_alloc");
+            return fail(ctx, GM_ERR_INVALID_ARG, "gm_set_cloud_output: the buffer must be page-locked (gm_host_alloc / gm_host_register)");
         }
     }
     if (xyzw && !sl.copy_stream) {
         GM_HIP(ctx, hipStreamCreateWithFlags(&sl.copy_stream, hipStreamNonBlocking));
+        GM_HIP(ctx, hipEventCreateWithFlags(&sl.ev_crop, hipEventDisableTiming));
         GM_HIP(ctx, hipEventCreateWithFlags(&sl.ev_valid, hipEventDisableTiming));
         GM_HIP(ctx, hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming));
+    }
+    sl.cloud_out_dev = nullptr;
+    if (xyzw) {   // the rows as the device addresses them (page-locked memory is mapped; without a mapping the copy stays a DMA)
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, xyzw, 0) == hipSuccess) sl.cloud_out_dev = reinterpret_cast<float4 *>(dp);
+        else (void)hipGetLastError();
     }
     sl.cloud_out = reinterpret_cast<float4 *>(xyzw);
     sl.cloud_out_cap = xyzw ? capacity : 0u;

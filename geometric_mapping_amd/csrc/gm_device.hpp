@@ -38,7 +38,7 @@ struct DevCounters {
     uint32_t n_cropped;   // points surviving the crop box
     uint32_t n_valid;     // points with a finite normal (and owned, when sharded)
     uint32_t n_tiles;     // (unused since the tile list has cost classes: n_tiles_c below)
-    uint32_t reserved0;
+    uint32_t first_drop_enc;   // 0xFFFFFFFF - (first cropped index without a finite normal); 0 = none (NaN-normal compaction)
     uint32_t n_voxels;    // occupied voxels
     uint32_t vox_n;       // points entering the voxel grid (= n_valid)
     uint32_t mm[6];       // ordered-uint encodings: min x,y,z then max x,y,z of the valid cloud

@@ -98,9 +98,10 @@ struct Slot {
     float4 *vox_nrm4 = nullptr;                       // [cap] normal of each voxel centroid's nearest point (GM_CFG_NEAREST)
     // /choppedCloud output (gm_set_cloud_output): caller-owned page-locked rows, copied on a stream of their own
     float4 *cloud_out = nullptr;
+    float4 *cloud_out_dev = nullptr;   // the same rows as the device sees them (mapped page-locked memory)
     uint32_t cloud_out_cap = 0;
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_valid = nullptr, ev_copied = nullptr;
+    hipEvent_t ev_crop = nullptr, ev_valid = nullptr, ev_copied = nullptr;
     // state
     bool submitted = false, complete = false;
     bool pipelined = false;      // the context keeps several frames in flight (n_slots > 1): kernels choose block shapes that share the chip
@@ -183,6 +184,7 @@ uint32_t launch_compact_valid(Slot &sl, uint32_t n_cap, double weightingFactor, 
 // scatter partials over vnorm4[0..n); returns the number of partial rows written
 uint32_t launch_scatter_partials(const float4 *vnorm4, const uint32_t *n_ptr, uint32_t n_cap, double wf, Slot &sl,
                                  hipStream_t s);
+void launch_rows_to_host(const float4 *src, float4 *dst_mapped, const uint32_t *begin_enc, const uint32_t *end_ptr, hipStream_t s);
 void launch_frame_finalize(const double *partials, uint32_t n_partials, uint32_t row_tile, Slot &sl, hipStream_t s);
 // k_voxel.hip
 void launch_voxel_grid(Slot &sl, uint32_t n_cap, float leaf, int key_bits, hipStream_t s);

@@ -22,13 +22,42 @@ namespace gm {
 // rank does not own, so slab ownership needs no test of its own.)  The normal rides to the emit step in registers.
 struct ValidPred {
     const float4 *__restrict__ normals4;
+    uint32_t *__restrict__ first_drop_enc;   // DevCounters::first_drop_enc: up to the first dropped point the valid cloud IS the cropped cloud
     typedef float4 Payload;
     __device__ __forceinline__ bool operator()(uint32_t i, Payload &p) const
     {
         p = normals4[i];
-        return finite3(p.x, p.y, p.z);
+        const bool ok = finite3(p.x, p.y, p.z);
+        if (!ok) {   // (rare on dense frames; a lane only adds what can still raise the maximum it last saw)
+            const uint32_t enc = 0xFFFFFFFFu - i;
+            if (*first_drop_enc < enc) atomicMax(first_drop_enc, enc);
+        }
+        return ok;
     }
 };
+
+// rows [begin, *end_ptr) of src -> dst, where dst is page-locked HOST memory mapped into the device's address space
+// (/choppedCloud, gm_set_cloud_output): 16-byte stores, consecutive lanes on consecutive rows, over PCIe.  A few blocks are
+// enough to fill the link and leave the chip to the frame's kernels.  begin_enc != nullptr: begin = 0xFFFFFFFF - *begin_enc
+// (DevCounters::first_drop_enc; 0 = nothing to copy).
+__global__ __launch_bounds__(256) void k_rows_to_host(const float4 *__restrict__ src, float4 *__restrict__ dst,
+                                                      const uint32_t *__restrict__ begin_enc, const uint32_t *__restrict__ end_ptr)
+{
+    const uint32_t end = *end_ptr;
+    uint32_t begin = 0;
+    if (begin_enc) {
+        const uint32_t e = *begin_enc;
+        if (e == 0u) return;
+        begin = 0xFFFFFFFFu - e;
+    }
+    for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+void launch_rows_to_host(const float4 *src, float4 *dst_mapped, const uint32_t *begin_enc, const uint32_t *end_ptr, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_rows_to_host, dim3(64), dim3(256), 0, s, src, dst_mapped, begin_enc, end_ptr);
+}
 
 // one term of getLocalFrame's scatter matrix (src/tunnel_processing.cpp:100-124) added to m[6]
 __device__ __forceinline__ void scatter_term(const float4 v /* nx,ny,nz,curvature */, double k_wf, double m[6])
@@ -144,7 +173,7 @@ uint32_t launch_compact_valid(Slot &sl, uint32_t n_cap, double wf, hipStream_t s
     if (row_tile) *row_tile = tile;
     const uint32_t nb = (n_cap + tile - 1) / tile;
     if (nb == 0) return 0;
-    ValidPred pred{sl.normals4};
+    ValidPred pred{sl.normals4, &sl.ctr->first_drop_enc};
     ValidEmit emit{sl.crop4, sl.valid4, sl.vnorm4, .001 / wf, sl.tile_partials, {0, 0, 0, 0, 0, 0}};
     if (big)
         hipLaunchKernelGGL((k_compact<ValidPred, ValidEmit, 1024, 8>), dim3(nb), dim3(1024), 0, s, pred, emit,

@@ -134,6 +134,11 @@ void gm_destroy(gm_ctx *ctx);
  * PointCloud2 rows).  Owned by the caller until gm_host_free; outlives nothing: free it before gm_destroy. */
 gm_status gm_host_alloc(gm_ctx *ctx, size_t bytes, void **out);
 gm_status gm_host_free(gm_ctx *ctx, void *ptr);
+/* The same for memory the caller already owns (e.g. the data vector of a pre-allocated sensor_msgs/PointCloud2 that a
+ * node publishes from: gm_set_cloud_output then delivers /choppedCloud straight into the message): page-locks
+ * [ptr, ptr + bytes) until gm_host_unregister.  Registered memory may be used wherever gm_host_alloc memory may. */
+gm_status gm_host_register(gm_ctx *ctx, void *ptr, size_t bytes);
+gm_status gm_host_unregister(gm_ctx *ctx, void *ptr);
 
 /* Defaults = the launch file's values (launch/mapping.launch:7-10). */
 void gm_default_config(gm_config *cfg);

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert set(names) == set(L._gm_proto), "ctypes prototypes and header drifted apart"
-    assert L.gm_abi_version() == 2
+    assert L.gm_abi_version() == 3
 
 
 def test_header_is_plain_c_and_struct_layouts_match_ctypes():

@@ -9,6 +9,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# (bench.py asks for 8 hardware queues from inside Python, but rocprofv3's preloaded library has initialised the runtime by
+# then: the profiled runs get the same 8 queues only if the variable is in the environment before rocprofv3 starts)
+export GPU_MAX_HW_QUEUES=8
 ARGS="--steps 50 --warmup 5 --no-cpu-baseline $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.log 2>&1 || exit 2
