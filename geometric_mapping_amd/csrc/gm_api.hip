@@ -649,14 +649,14 @@ gm_status gm_ensure_ext(gm_ctx *ctx, Slot &sl, uint32_t H)
     sl.ext_H = 0; sl.ext_cap = 0;
     GM_HIP(ctx, dmalloc(sl.hyp_plane, (size_t)HH * 8)); GM_HIP(ctx, dmalloc(sl.hyp_cyl, (size_t)HH * 8));
     GM_HIP(ctx, dmalloc(sl.band, HH));
-    GM_HIP(ctx, dmalloc(sl.score_partial, (size_t)1024));  // pre-selection scratch (k_ransac.hip kPreScratchWords = 576)
+    GM_HIP(ctx, dmalloc(sl.score_partial, (size_t)4096));  // pre-selection scratch (k_ransac.hip kPre*: 577 words, replicated counters at 1024)
     GM_HIP(ctx, dmalloc(sl.cnt_plane, HH)); GM_HIP(ctx, dmalloc(sl.cnt_cyl, HH));
     GM_HIP(ctx, dmalloc(sl.best_plane, 2)); GM_HIP(ctx, dmalloc(sl.best_cyl, 2));
     GM_HIP(ctx, dmalloc(sl.mom_partial, (size_t)kScatterBlocks * 16 * 2));  // [model][row][16]
     GM_HIP(ctx, dmalloc(sl.mom_plane, 16)); GM_HIP(ctx, dmalloc(sl.mom_cyl, 16));
     GM_HIP(ctx, dmalloc(sl.nn_best, sl.cap));
     GM_HIP(ctx, dmalloc(sl.vox_nrm4, sl.cap));
-    GM_HIP(ctx, hipMemset(sl.score_partial, 0, sizeof(uint32_t) * 1024));  // (holds the scoring launches' done-counter)
+    GM_HIP(ctx, hipMemset(sl.score_partial, 0, sizeof(uint32_t) * 4096));  // (holds the scoring launches' done-counter)
     GM_HIP(ctx, hipMemset(sl.best_plane, 0xFF, 8));
     GM_HIP(ctx, hipMemset(sl.best_cyl, 0xFF, 8));
     sl.ext_H = HH; sl.ext_cap = sl.cap;

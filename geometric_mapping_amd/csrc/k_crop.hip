@@ -43,20 +43,6 @@ struct RowReader {
     }
 };
 
-// CropBox::applyFilter: outside iff any coordinate < min or > max (closed box);
-// NaN rows dropped (see gm_hip.h / DESIGN.md for the dense-flag caveat).
-struct CropPred {
-    RowReader rd;
-    float lo, hi;
-    struct Payload { float x, y, z; };   // the row's coordinates: the emit step writes them, the rows are read once
-    __device__ __forceinline__ bool operator()(uint32_t i, Payload &p) const
-    {
-        rd.load(i, p.x, p.y, p.z);
-        if (!finite3(p.x, p.y, p.z)) return false;
-        return !(p.x < lo || p.y < lo || p.z < lo || p.x > hi || p.y > hi || p.z > hi);
-    }
-};
-
 // digit counters of the block: [pass][bin] for the passes of the cell sort (k_sort.hip radix_plan)
 __device__ __forceinline__ uint32_t *crop_digit_hist()
 {
@@ -64,15 +50,36 @@ __device__ __forceinline__ uint32_t *crop_digit_hist()
     return h;
 }
 
+// CropBox::applyFilter: outside iff any coordinate < min or > max (closed box);
+// NaN rows dropped (see gm_hip.h / DESIGN.md for the dense-flag caveat).
+struct CropPred {
+    RowReader rd;
+    float lo, hi;
+    GridParams g;
+    // The digit totals of the cell sort's first pass do not depend on the order of the keys, and the key of a survivor
+    // is known right here: the block counts them in LDS (zeroed by CropEmit::prepare, added to the totals the pass starts
+    // from by CropEmit::finish) -- in THIS phase, in front of the chained scan's look-back, where the block would wait
+    // anyway (counting in the emit step, behind the look-back, cost the 10 M-point crop 8 us).  count_bits == 0: not asked for.
+    uint32_t count_bits;
+    struct Payload { float x, y, z; uint32_t key; };   // the row's coordinates and cell key: the emit step writes them, the rows are read once
+    __device__ __forceinline__ bool operator()(uint32_t i, Payload &p) const
+    {
+        rd.load(i, p.x, p.y, p.z);
+        if (!finite3(p.x, p.y, p.z)) return false;
+        if (p.x < lo || p.y < lo || p.z < lo || p.x > hi || p.y > hi || p.z > hi) return false;
+        p.key = cell_key(g, p.x, p.y, p.z);
+        if (count_bits) atomicAdd(&crop_digit_hist()[p.key & ((1u << count_bits) - 1u)], 1u);
+        return true;
+    }
+};
+
 struct CropEmit {
     static constexpr bool kHasFinish = true, kHasPrepare = true;
     RowReader rd;
     GridParams g;
     float4 *__restrict__ crop4;
     uint32_t *__restrict__ keys;
-    // The digit totals of every pass of the cell sort do not depend on the order of the keys, and the keys are in
-    // registers here: the block counts them in LDS as it emits and adds its counts to the totals the sort's passes start
-    // from (plan.passes == 0: not asked for).  The sort then needs no histogram launch at all.
+    // the block's digit counts (CropPred) -> the totals the cell sort's first pass starts from; plan.passes == 0: not asked for
     SortPlan plan;
     uint32_t *__restrict__ totals;   // [pass][2048]
     __device__ __forceinline__ void prepare() const
@@ -101,14 +108,7 @@ struct CropEmit {
     __device__ __forceinline__ void operator()(uint32_t src, uint32_t dst, const CropPred::Payload &p) const
     {
         crop4[dst] = make_float4(p.x, p.y, p.z, __uint_as_float(src));
-        const uint32_t key = cell_key(g, p.x, p.y, p.z);
-        keys[dst] = key;
-        if (plan.passes) {
-            uint32_t *h = crop_digit_hist();
-            const uint32_t bins = 1u << plan.bits;
-#pragma unroll 4
-            for (int q = 0; q < plan.passes; ++q) atomicAdd(&h[((uint32_t)q << plan.bits) + ((key >> (q * plan.bits)) & (bins - 1u))], 1u);
-        }
+        keys[dst] = p.key;
     }
 };
 
@@ -142,8 +142,9 @@ void launch_crop(const RowLayout &rows, uint32_t n, float lo, float hi, const Gr
     if (n_size < n) n_size = n;
     if (n_size == 0) return;  // counters were zeroed: n_cropped stays 0
     RowReader rd{rows};
-    CropPred pred{rd, lo, hi};
-    CropEmit emit{rd, g, sl.crop4, sl.keys_a, count_digits ? radix_plan(cell_key_bits(g)) : SortPlan{0, 0}, sl.sort.totals};
+    CropPred pred{rd, lo, hi, g, count_digits ? (uint32_t)radix_plan(cell_key_bits(g)).bits : 0u};
+    // (the digit totals of the cell sort's FIRST pass only: the pass itself counts the later ones, k_sort.hip)
+    CropEmit emit{rd, g, sl.crop4, sl.keys_a, count_digits ? SortPlan{1, radix_plan(cell_key_bits(g)).bits} : SortPlan{0, 0}, sl.sort.totals};
     // Tile shape: 512 threads x 8 rows, and 1024 x 8 for frames beyond 2 M points.  Every tile costs a ticket and a
     // look-back; with every block slot of the chip taken (2.4 rounds of 4096-point tiles at 10 M points) twice the tile
     // is 107 -> 80 us on the 10 M-point frame and 34.5 -> 31 us at 3 M, while the 1 M-point frame (204 tiles for 256 CUs)

@@ -206,6 +206,7 @@ struct SelectNext {
     uint32_t M, K;
     uint32_t *sel;             // nullptr: no selection folded into this launch
     int32_t *counts_out;
+    uint32_t zero_n;           // words of counts_out to clear (0: K) -- the streaming last stage keeps replicated counters
 };
 inline uint32_t select_lds_bytes(uint32_t) { return 0u; }   // (the keys live in registers)
 constexpr uint32_t kSelectFoldMax = 2048;  // candidates (8 keys per thread of a 256-thread block); above that a k_select_topk launch does it
@@ -262,7 +263,7 @@ __device__ __forceinline__ void select_by_last_block(const int32_t *__restrict__
     }
     if (my_or) atomicOr(&s_or, my_or);
     for (uint32_t t = threadIdx.x; t < 256u; t += T) s_hist[t >> 4][t & 15u] = 0u;
-    for (uint32_t r = threadIdx.x; r < nx.K; r += T) nx.counts_out[r] = 0;
+    for (uint32_t r = threadIdx.x; r < (nx.zero_n ? nx.zero_n : nx.K); r += T) nx.counts_out[r] = 0;
     __syncthreads();
     unsigned long long kth = 0ull;  // K >= M: everything is selected
     if (nx.K < nx.M) {
@@ -442,7 +443,8 @@ constexpr int kPre1Stride = 64, kPre1Keep = 128;
 constexpr int kPre2Stride = 16, kPre2Keep = 8;
 // scratch layout (uint32 words): selA[256] cntA[256] selB[32] cntB[32]
 constexpr int kPreSelA = 0, kPreCntA = 256, kPreSelB = 512, kPreCntB = 544;  // 576 words, then
-constexpr int kPreDone = 576;  // the done-counter of select_by_last_block: zero between launches (gm_ensure_ext allocates 1024 zeroed words)
+constexpr int kPreDone = 576;  // the done-counter of select_by_last_block: zero between launches (gm_ensure_ext allocates 4096 zeroed words)
+constexpr int kPreCntStream = 1024;  // the streaming last stage's replicated counters: kStReplicas x kStReplicaStride words
 
 // Top-K of M scored candidates.  Candidate i has count counts[i] and hypothesis index ids ? ids[i] : i; order =
 // count descending, hypothesis index ascending.  sel[rank] = hypothesis index; block 0 also clears counts_out[0..K).
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(256) void k_select_topk(const int32_t *__restrict__
     uint32_t *li = reinterpret_cast<uint32_t *>(lc + M);
     for (uint32_t i = threadIdx.x; i < M; i += 256) { lc[i] = counts[i]; li[i] = ids ? ids[i] : i; }
     if (blockIdx.x == 0)
-        for (uint32_t k = threadIdx.x; k < K; k += 256) counts_out[k] = 0;  // the next stage's counters start at zero
+        for (uint32_t k = threadIdx.x; k < K; k += 256) counts_out[k] = 0;  // the next stage's counters start at zero (not the replicated ones: see launch_score_preemptive)
     __syncthreads();
     const uint32_t i = blockIdx.x * 16u + threadIdx.x / 16u, part = threadIdx.x & 15u;
     const int32_t c = i < M ? lc[i] : 0;
@@ -557,6 +559,11 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
 // written per point.  (lane <-> hypothesis over LDS-staged points -- k_score_sel, the shape of the stages with 1024 / 128
 // hypotheses -- scored these 8 at 17-22 % of the memory roofline on the 10 M-point frame: bound by neither.)
 constexpr int kStThreads = 256, kStPer = 4, kStK = 8;
+// A block ends with one integer atomic per hypothesis; on ONE word per hypothesis they are served one after the other
+// (~12 ns each): 814 blocks made the 1 M-point launch 16.7 us, and a grid capped at 256 blocks left too few loads in
+// flight on the 10 M-point frame (155 us for 133 MB).  The counters are kept in kStReplicas copies, 128 bytes apart --
+// block b adds to copy b % kStReplicas -- and the label pass, the only reader, sums the copies.
+constexpr int kStReplicas = 32, kStReplicaStride = 32;   // words
 template <int MODEL>
 __global__ __launch_bounds__(kStThreads) void k_score_stream(const float4 *__restrict__ pts, const uint8_t *__restrict__ labels,
                                                              uint32_t want, const uint32_t *__restrict__ n_ptr, uint32_t n_host,
@@ -584,6 +591,7 @@ __global__ __launch_bounds__(kStThreads) void k_score_stream(const float4 *__res
 #pragma unroll
     for (int k = 0; k < kStK; ++k) cnt[k] = 0u;
     const uint32_t span = (uint32_t)(kStThreads * kStPer);
+    // (loading the block's next span before scoring the current one was measured on the 10 M-point frame: no gain)
     for (uint32_t base = blockIdx.x * span; base < n; base += gridDim.x * span) {   // uniform per block
         float4 p[kStPer];
         bool ok[kStPer];
@@ -619,7 +627,7 @@ __global__ __launch_bounds__(kStThreads) void k_score_stream(const float4 *__res
         uint32_t t = 0;
 #pragma unroll
         for (int j = 0; j < kStThreads / kWave; ++j) t += red[j][threadIdx.x];
-        if (t) atomicAdd(&counts_k[threadIdx.x], (int32_t)t);
+        if (t) atomicAdd(&counts_k[(blockIdx.x % (uint32_t)kStReplicas) * (uint32_t)kStReplicaStride + threadIdx.x], (int32_t)t);
     }
 }
 
@@ -641,7 +649,7 @@ __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, u
                                                float tau, int init, const int32_t *__restrict__ counts_k,
                                                const uint32_t *__restrict__ sel, uint32_t K,
                                                const float4 *__restrict__ nrm, double *__restrict__ mom_partial,
-                                               const uint8_t *__restrict__ masks)
+                                               const uint8_t *__restrict__ masks, uint32_t replicas)
 {
     const uint32_t n = n_ptr ? *n_ptr : n_host;
     uint32_t h, wbit = 0;
@@ -649,7 +657,10 @@ __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, u
         __shared__ uint32_t win[3];
         if (threadIdx.x < kWave) {
             uint32_t c = 0, hi = 0xFFFFFFFFu, sl = threadIdx.x;
-            if (threadIdx.x < K) { c = (uint32_t)counts_k[threadIdx.x]; hi = sel[threadIdx.x]; }
+            if (threadIdx.x < K) {
+                for (uint32_t r = 0; r < replicas; ++r) c += (uint32_t)counts_k[r * (uint32_t)kStReplicaStride + threadIdx.x];
+                hi = sel[threadIdx.x];
+            }
 #pragma unroll
             for (int o = 1; o < kWave; o <<= 1) {
                 const uint32_t oc = __shfl_xor(c, o, kWave), oh = __shfl_xor(hi, o, kWave), os = __shfl_xor(sl, o, kWave);
@@ -679,6 +690,18 @@ __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, u
 #pragma unroll
     for (int k = 0; k < NM; ++k) m[k] = 0.0;
     const bool by_mask = masks != nullptr && counts_k != nullptr;   // uniform
+    auto add_moments = [&](const float4 p, uint32_t i) {
+        const double x = p.x, y = p.y, z = p.z;
+        m[0] += 1.0; m[1] += x; m[2] += y; m[3] += z;
+        m[4] += x * x; m[5] += x * y; m[6] += x * z; m[7] += y * y; m[8] += y * z; m[9] += z * z;
+        if (MODEL == 1) {
+            const float4 q = nrm[i];
+            const double u = q.x, v = q.y, w = q.z;
+            m[10] += u * u; m[11] += u * v; m[12] += u * w; m[13] += v * v; m[14] += v * w; m[15] += w * w;
+        }
+    };
+    // (four points per thread and trip -- all masks, then all rows -- was measured on the 10 M-point frame: 56.7 -> 67.6 us
+    // for the cylinder label, 35.5 -> 37.1 for the plane's; one point per trip it stays)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         bool in;
         float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -694,16 +717,7 @@ __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, u
         }
         if (init) labels[i] = in ? (uint8_t)label : (uint8_t)0;
         else if (in) labels[i] = (uint8_t)label;
-        if (MOM && in) {
-            const double x = p.x, y = p.y, z = p.z;
-            m[0] += 1.0; m[1] += x; m[2] += y; m[3] += z;
-            m[4] += x * x; m[5] += x * y; m[6] += x * z; m[7] += y * y; m[8] += y * z; m[9] += z * z;
-            if (MODEL == 1) {
-                const float4 q = nrm[i];
-                const double u = q.x, v = q.y, w = q.z;
-                m[10] += u * u; m[11] += u * v; m[12] += u * w; m[13] += v * v; m[14] += v * w; m[15] += w * w;
-            }
-        }
+        if (MOM && in) add_moments(p, i);
     }
     if (MOM) {
         __shared__ double red[256 / kWave][16];
@@ -964,31 +978,35 @@ bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels
     const float2 *cb = band;
     const uint32_t K2 = kPre2Keep;
     uint32_t *done = scratch + kPreDone;
+    static const char *fs = getenv("GM_RANSAC_FINAL");   // "sel": the last stage in the lane <-> hypothesis shape (A/B timing)
+    const bool stream = masks && K2 <= (uint32_t)kStK && !(fs && fs[0] == 's');
+    if (stream) cntB = (int32_t *)(scratch + kPreCntStream);
+    const uint32_t zeroB = stream ? (uint32_t)(kStReplicas * kStReplicaStride) : 0u;
     const SelectNext none{};
     // (a selection over more than kSelectFoldMax candidates keeps its own launch: the LDS sort would not fit)
     if (H > (uint32_t)kPre1Keep) {
         const uint32_t K1 = kPre1Keep;
         static const char *own = getenv("GM_RANSAC_SELECT");   // "kernel": selections keep their own launches (A/B timing)
         const bool fold = H <= kSelectFoldMax && !(own && own[0] == 'k');
-        const SelectNext n1{done, nullptr, H, K1, selA, cntA}, n2{done, selA, K1, K2, selB, cntB};
+        const SelectNext n1{done, nullptr, H, K1, selA, cntA, 0u}, n2{done, selA, K1, K2, selB, cntB, zeroB};
         if (model == 0) score_stage_all<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre1Stride, counts, fold ? n1 : none, s);
         else score_stage_all<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre1Stride, counts, fold ? n1 : none, s);
         if (!fold) select_topk(counts, nullptr, H, K1, selA, cntA, s);
         if (model == 0) score_stage_sel<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selA, K1, tau, kPre2Stride, cntA, fold ? n2 : none, s);
         else score_stage_sel<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selA, K1, tau, kPre2Stride, cntA, fold ? n2 : none, s);
-        if (!fold) select_topk(cntA, selA, K1, K2, selB, cntB, s);
+        if (!fold) {
+            select_topk(cntA, selA, K1, K2, selB, cntB, s);
+            if (stream) (void)hipMemsetAsync(cntB, 0, sizeof(int32_t) * zeroB, s);
+        }
     } else {
-        const SelectNext n2{done, nullptr, H, K2, selB, cntB};
+        const SelectNext n2{done, nullptr, H, K2, selB, cntB, zeroB};
         if (model == 0) score_stage_all<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre2Stride, counts, n2, s);
         else score_stage_all<1>(pts, labels, want, n_ptr, n_cap, hyp8, cb, H, tau, kPre2Stride, counts, n2, s);
     }
-    static const char *fs = getenv("GM_RANSAC_FINAL");   // "sel": the last stage in the lane <-> hypothesis shape (A/B timing)
-    if (masks && K2 <= (uint32_t)kStK && !(fs && fs[0] == 's')) {
+    if (stream) {
         // the last stage streams: lane <-> point, hypotheses in scalar registers (k_score_stream); also leaves the inlier masks
-        // (every block ends with one atomic per hypothesis on the same K words, ~12 ns each and one after the other: 814
-        // blocks of 1024 points made the 1 M-point launch 16.7 us.  A block per CU walks its share of the points instead.)
         uint32_t nb = (n_cap + kStThreads * kStPer - 1) / (kStThreads * kStPer);
-        if (nb > 256u) nb = 256u;
+        if (nb > 2048u) nb = 2048u;   // (8 waves per CU: 32 MB of loads in flight)
         if (nb == 0) nb = 1;
         if (model == 0)
             hipLaunchKernelGGL(k_score_stream<0>, dim3(nb), dim3(kStThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8, cb,
@@ -1025,7 +1043,7 @@ uint32_t launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t wa
     if (nb == 0) nb = 1;
 #define GM_LABEL(M, MO)                                                                                                 \
     hipLaunchKernelGGL((k_label<M, MO>), dim3(nb), dim3(256), 0, s, pts, labels, want, label, n_ptr, n_cap, hyp8, band, \
-                       best, (float)tau, init, counts_k, sel, K, nrm, mom_partial, masks)
+                       best, (float)tau, init, counts_k, sel, K, nrm, mom_partial, masks, masks ? (uint32_t)kStReplicas : 1u)
     if (model == 0) { if (mom_partial) GM_LABEL(0, 1); else GM_LABEL(0, 0); }
     else { if (mom_partial) GM_LABEL(1, 1); else GM_LABEL(1, 0); }
 #undef GM_LABEL

@@ -9,8 +9,8 @@
 //
 // A pass is one kernel (k_rs_pass), a block per tile of 8192 consecutive positions:
 //   * the digit TOTALS of every pass are known before the first pass starts -- they do not depend on the order of
-//     the keys: the crop's emit step counts them as it produces the keys (k_crop.hip), any other caller runs
-//     k_rs_hist_all (one read of the keys for all passes);
+//     the keys: the crop's emit step counts the first pass's as it produces the keys (k_crop.hip), the first pass those
+//     of the passes after it as it reads the keys; any other caller runs k_rs_hist_all (one read for all passes);
 //   * a block counts its tile's digits per wave in LDS, publishes the tile's count of every digit as one 64-bit
 //     record [epoch:30 | state:2 | count:32] and looks back over the records of the tiles before it, one digit per
 //     thread, 16 records in flight (decoupled look-back, as gm_compact.hpp does for one counter): the tile's items of
@@ -137,7 +137,8 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_pass(const uint32_t *__restri
                                                         const uint32_t *__restrict__ n_ptr, int shift,
                                                         const uint32_t *__restrict__ totals, uint32_t *__restrict__ rec,
                                                         uint32_t *__restrict__ ticket,
-                                                        const float4 *__restrict__ rows_in, float4 *__restrict__ rows_out)
+                                                        const float4 *__restrict__ rows_in, float4 *__restrict__ rows_out,
+                                                        uint32_t *__restrict__ totals_later, int count_later)
 {
     constexpr int BINS = 1 << BITS;
     constexpr int kRsWaves = kRsThreads / kWave, kRsTile = kRsThreads * kRsItems;
@@ -153,6 +154,10 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_pass(const uint32_t *__restri
     __shared__ __attribute__((aligned(16))) uint32_t lbq[GROUPS][OCTS][4];   // look-back: the groups' packed partial sums; also the rows being published
     __shared__ uint32_t wsum_b[kRsWaves], wsum_t[kRsWaves];
     __shared__ uint32_t s_tile, s_more;
+    // count_later > 0 (the first pass of a sort whose pass-0 totals came from the crop): this pass reads every key anyway
+    // and counts the digits of the count_later passes after it -- their totals do not depend on the order of the keys --
+    // so the crop's emit step counts one digit per survivor instead of all of them
+    __shared__ uint32_t later[kRsMaxPasses - 1][BINS];
     uint32_t *const skey = stage, *const sval = stage + kRsTile;
     unsigned long long *const lmask = reinterpret_cast<unsigned long long *>(stage);
 #ifdef GM_SORT_TIMELINE
@@ -172,6 +177,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_pass(const uint32_t *__restri
     const bool has_digit = half == 0;
     const uint32_t tot = has_digit ? totals[dig] : 0u;   // (does not depend on the tile: in flight behind the ticket)
     for (int k = threadIdx.x; k < kRsWaves * BINS; k += kRsThreads) { (&cw[0][0])[k] = 0; lmask[k] = 0ull; }
+    for (int k = threadIdx.x; k < count_later * BINS; k += kRsThreads) (&later[0][0])[k] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
     if (tile >= ntiles) return;   // uniform per block; nothing after the end is ever looked at
@@ -195,6 +201,14 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_pass(const uint32_t *__restri
     for (int u = 0; u < kRsItems; ++u) {
         const uint32_t i = wbase + (uint32_t)u * kWave + lane;
         if (i < n) atomicAdd(&cw[w][(kk[u] >> shift) & (BINS - 1)], 1u);
+    }
+    if (count_later) {   // uniform
+#pragma unroll
+        for (int u = 0; u < kRsItems; ++u) {
+            const uint32_t i = wbase + (uint32_t)u * kWave + lane;
+            if (i < n)
+                for (int q = 0; q < count_later; ++q) atomicAdd(&later[q][(kk[u] >> (shift + (q + 1) * BITS)) & (BINS - 1)], 1u);
+        }
     }
     if (threadIdx.x == 0) s_more = 0u;
     __syncthreads();
@@ -362,6 +376,12 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_pass(const uint32_t *__restri
             }
         }
     }
+    if (count_later) {   // (every thread passed the barriers above: the counts are complete)
+        for (int k = threadIdx.x; k < count_later * BINS; k += kRsThreads) {
+            const uint32_t cq = (&later[0][0])[k];
+            if (cq) atomicAdd(&totals_later[(uint32_t)(k / BINS) * (uint32_t)kRsTotalsStride + (uint32_t)(k % BINS)], cq);
+        }
+    }
 #ifdef GM_SORT_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GM_ST_STAMP(7);   // stores acknowledged
@@ -371,14 +391,14 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_pass(const uint32_t *__restri
 template <int BITS, int THREADS>
 static void rs_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, const uint32_t *n_ptr,
                     int shift, uint32_t nb, const uint32_t *totals, uint32_t *rec, uint32_t *ticket,
-                    const float4 *rows_in, float4 *rows_out, hipStream_t s)
+                    const float4 *rows_in, float4 *rows_out, uint32_t *totals_later, int count_later, hipStream_t s)
 {
     if (rows_out)
         hipLaunchKernelGGL((k_rs_pass<BITS, true, THREADS>), dim3(nb), dim3(THREADS), 0, s, kin, vin, kout, vout, n_ptr, shift, totals,
-                           rec, ticket, rows_in, rows_out);
+                           rec, ticket, rows_in, rows_out, totals_later, count_later);
     else
         hipLaunchKernelGGL((k_rs_pass<BITS, false, THREADS>), dim3(nb), dim3(THREADS), 0, s, kin, vin, kout, vout, n_ptr, shift, totals,
-                           rec, ticket, rows_in, rows_out);
+                           rec, ticket, rows_in, rows_out, totals_later, count_later);
 }
 
 // Sorts (keys_a, index) by the low key_bits bits of the keys.  Returns 0 if the sorted keys (and values) end in
@@ -413,12 +433,15 @@ int launch_radix_sort(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint
         const bool last = p + 1 == plan.passes;
         const float4 *ri = last ? rows_in : nullptr;
         float4 *ro = last ? rows_out : nullptr;
+        // (prepared: the crop counted pass 0's digits only; pass 0 counts those of the passes after it)
+        uint32_t *tl = totals + (size_t)(p + 1) * kRsTotalsStride;
+        const int cl = (prepared && p == 0) ? plan.passes - 1 : 0;
         if (threads == 1024) {
-            if (plan.bits == 8) rs_pass<8, 1024>(kin, vin, kout, vout, n_ptr, shift, nb, tot, rec, sl.sort.ticket, ri, ro, s);
-            else rs_pass<9, 1024>(kin, vin, kout, vout, n_ptr, shift, nb, tot, rec, sl.sort.ticket, ri, ro, s);
+            if (plan.bits == 8) rs_pass<8, 1024>(kin, vin, kout, vout, n_ptr, shift, nb, tot, rec, sl.sort.ticket, ri, ro, tl, cl, s);
+            else rs_pass<9, 1024>(kin, vin, kout, vout, n_ptr, shift, nb, tot, rec, sl.sort.ticket, ri, ro, tl, cl, s);
         } else {
-            if (plan.bits == 8) rs_pass<8, 512>(kin, vin, kout, vout, n_ptr, shift, nb, tot, rec, sl.sort.ticket, ri, ro, s);
-            else rs_pass<9, 512>(kin, vin, kout, vout, n_ptr, shift, nb, tot, rec, sl.sort.ticket, ri, ro, s);
+            if (plan.bits == 8) rs_pass<8, 512>(kin, vin, kout, vout, n_ptr, shift, nb, tot, rec, sl.sort.ticket, ri, ro, tl, cl, s);
+            else rs_pass<9, 512>(kin, vin, kout, vout, n_ptr, shift, nb, tot, rec, sl.sort.ticket, ri, ro, tl, cl, s);
         }
         if (p == 0) { kin = keys_b; vin = vals_b; kout = keys_a; vout = vals_a; }
         else {
