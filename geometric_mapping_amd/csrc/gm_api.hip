@@ -601,12 +601,15 @@ gm_status check_slot(gm_ctx *ctx, uint32_t slot)
     return wait_slot(ctx, ctx->slots[slot]);
 }
 
-// stage calls reuse slot 0 and leave it "not submitted"
+// stage calls reuse slot 0 and leave it "not submitted".  A frame submitted to slot 0 and not yet waited for owns the slot's
+// buffers: the stage call is refused (it used to overwrite them and drop the frame's result).
 gm_status begin_stage(gm_ctx *ctx, Slot *&sl)
 {
     if (!ctx) return GM_ERR_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, GM_ERR_DEVICE, "hipSetDevice failed");
     sl = &ctx->slots[0];
+    if (sl->submitted && !sl->complete)
+        return fail(ctx, GM_ERR_NOT_READY, "slot 0 holds a submitted frame that has not been waited for (gm_wait_frame first)");
     GM_HIP(ctx, hipStreamSynchronize(sl->stream));
     sl->submitted = false;
     sl->complete = false;

@@ -466,7 +466,14 @@ gm_status gm_group_process_frame(gm_group *grp, const gm_cloud *cloud, gm_frame_
     const double t0 = now_ms();
     CutPlan plan;
     std::vector<uint32_t> total;
-    gm_status st = cut_rows(G, cloud, plan, total);
+    gm_status st;
+    try {   // (the cut allocates and starts threads: nothing may leave through the C ABI)
+        st = cut_rows(G, cloud, plan, total);
+    } catch (const std::bad_alloc &) {
+        return gfail(grp, GM_ERR_OOM, "gm_group_process_frame: host allocation failed in the slab cut");
+    } catch (const std::exception &e) {
+        return gfail(grp, GM_ERR_DEVICE, std::string("gm_group_process_frame: the slab cut failed: ") + e.what());
+    }
     if (st != GM_OK) return st;
     G.edges = plan.edges;
     G.edges_on_lattice = plan.on_lattice;

@@ -926,7 +926,10 @@ static void score_stage_all(const float4 *pts, const uint8_t *labels, uint32_t w
     uint32_t tile = (uint32_t)kScTile;
     while (tile > 32u && (uint64_t)((n_sub + tile - 1) / tile) * hy < 512u) tile >>= 1;
     static const char *te = getenv("GM_RANSAC_TILE");   // experiments
-    if (te) tile = (uint32_t)atoi(te);
+    if (te) {   // (a multiple of 4 in [32, kScTile]: anything else is not a tile the kernel can walk)
+        const int tv = atoi(te);
+        if (tv >= 32 && tv <= kScTile && (tv & 3) == 0) tile = (uint32_t)tv;
+    }
     const uint32_t nb = (n_sub + tile - 1) / tile ? (n_sub + tile - 1) / tile : 1;
     hipLaunchKernelGGL(k_score<MODEL>, dim3(nb, hy), dim3(kScThreads),
                        next.sel ? select_lds_bytes(next.M) : 0u, s, pts, labels, want, n_ptr, n_cap, hyp8, band, H,

@@ -721,3 +721,20 @@ def test_lidar_shaped_organised_cloud_matches_oracle(gm, oc, rings, az, step, pa
     assert abs(res["eigenvalues"][2] - ev[2]) / ev[2] < 1e-5 and abs(res["eigenvalues"][1] - ev[1]) / ev[1] < 1e-5
     ax, oax = res["center_axis"].astype(np.float64), o["evecs"][:, 0].astype(np.float64)
     assert np.linalg.norm(np.cross(ax, oax)) / (np.linalg.norm(ax) * np.linalg.norm(oax)) < 1e-5
+
+
+def test_stage_call_does_not_clobber_a_submitted_frame(gm):
+    """The stage calls work in slot 0.  While a frame submitted to slot 0 has not been waited for they are refused
+    (GM_ERR_NOT_READY) instead of overwriting the slot's buffers; the frame's result stays intact."""
+    from geometric_mapping_amd import _lib
+    xyz = synth.tunnel_frame(40000, seed=5, outlier_frac=0.01)
+    with gm.GeometricMapping(neighborRadius=0.3) as c:
+        ref = c.process_frame(xyz)
+        c.submit_frame(0, xyz)
+        with pytest.raises(gm.GmError) as e:
+            c.chopCloud(5.0, xyz[:100])
+        assert e.value.status == _lib.GM_ERR_NOT_READY
+        r = c.wait_frame(0)
+        assert r["n_valid"] == ref["n_valid"] and np.array_equal(r["scatter6"], ref["scatter6"])
+        out, rows = c.chopCloud(5.0, xyz[:100])            # after the wait the slot is free again
+        assert len(out) == len(rows) <= 100
