@@ -684,22 +684,22 @@ gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap, uint32_t scat
     if (do_plane) {
         uint8_t *lab = first ? nullptr : sl.labels;
         launch_plane_hypotheses(sl.valid4, lab, 0, n_ptr, n_cap, cf.ransac_seed, H, sl.hyp_plane, sl.cnt_plane, s);
-        const uint32_t *fsel = nullptr; const int32_t *fcnt = nullptr; uint32_t fk = 0; bool fmask = false;
+        const uint32_t *fsel = nullptr; const int32_t *fcnt = nullptr; uint32_t fk = 0; bool fmask = false, frep = false;
         launch_score_preemptive(0, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_plane, sl.band, H, cf.ransac_threshold,
-                                sl.score_partial, sl.cnt_plane, sl.best_plane, true, &fsel, &fcnt, &fk, s, sl.inl_mask, &fmask);
+                                sl.score_partial, sl.cnt_plane, sl.best_plane, true, &fsel, &fcnt, &fk, s, sl.inl_mask, &fmask, &frep);
         mom_rows = launch_label(0, sl.valid4, sl.labels, 0, 1, n_ptr, n_cap, sl.hyp_plane, sl.band, sl.best_plane,
-                                cf.ransac_threshold, first ? 1 : 0, fsel, fcnt, fk, s, sl.vnorm4, sl.mom_partial, fmask ? sl.inl_mask : nullptr);
+                                cf.ransac_threshold, first ? 1 : 0, fsel, fcnt, fk, s, sl.vnorm4, sl.mom_partial, fmask ? sl.inl_mask : nullptr, frep);
         first = false;
     }
     if (do_cyl) {
         uint8_t *lab = first ? nullptr : sl.labels;
         launch_cylinder_hypotheses(sl.valid4, sl.vnorm4, lab, 0, n_ptr, n_cap, cf.ransac_seed + 1, H, sl.hyp_cyl,
                                    sl.cnt_cyl, sl.band, cf.ransac_threshold, s);
-        const uint32_t *fsel = nullptr; const int32_t *fcnt = nullptr; uint32_t fk = 0; bool fmask = false;
+        const uint32_t *fsel = nullptr; const int32_t *fcnt = nullptr; uint32_t fk = 0; bool fmask = false, frep = false;
         launch_score_preemptive(1, sl.valid4, lab, 0, n_ptr, n_cap, sl.hyp_cyl, sl.band, H, cf.ransac_threshold,
-                                sl.score_partial, sl.cnt_cyl, sl.best_cyl, true, &fsel, &fcnt, &fk, s, sl.inl_mask, &fmask);
+                                sl.score_partial, sl.cnt_cyl, sl.best_cyl, true, &fsel, &fcnt, &fk, s, sl.inl_mask, &fmask, &frep);
         mom_rows = launch_label(1, sl.valid4, sl.labels, 0, 2, n_ptr, n_cap, sl.hyp_cyl, sl.band, sl.best_cyl,
-                                cf.ransac_threshold, first ? 1 : 0, fsel, fcnt, fk, s, sl.vnorm4, sl.mom_partial, fmask ? sl.inl_mask : nullptr);
+                                cf.ransac_threshold, first ? 1 : 0, fsel, fcnt, fk, s, sl.vnorm4, sl.mom_partial, fmask ? sl.inl_mask : nullptr, frep);
         first = false;
     }
     // the label passes left the moments of their segments in sl.mom_partial (one row per block, the same grid for both

@@ -206,12 +206,13 @@ bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels
                              const uint32_t *n_ptr, uint32_t n_cap, const float *hyp8, float2 *band, uint32_t H,
                              double tau, uint32_t *scratch, int32_t *counts, uint32_t *best, bool prepared,
                              const uint32_t **sel_out, const int32_t **cnt_out, uint32_t *k_out, hipStream_t s,
-                             uint8_t *masks = nullptr, bool *masks_written = nullptr);   // masks: the last stage streams and leaves every point's inlier mask there
+                             uint8_t *masks = nullptr, bool *masks_written = nullptr, bool *replicated_counts = nullptr);
+                             // masks != nullptr: the last stage streams (k_score_stream; its counters are then kept in copies) and may leave inlier masks
 uint32_t launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, uint32_t label, const uint32_t *n_ptr,
                       uint32_t n_cap, const float *hyp8, const float2 *band, uint32_t *best, double tau, int init,
                       const uint32_t *sel, const int32_t *counts_k, uint32_t K, hipStream_t s,
                       const float4 *nrm = nullptr, double *mom_partial = nullptr,
-                      const uint8_t *masks = nullptr);  // returns the grid size (= partial rows); masks: of the K hypotheses in sel
+                      const uint8_t *masks = nullptr, bool replicated_counts = false);  // returns the grid size (= partial rows); masks: of the K hypotheses in sel
 void launch_segment_moments(const float4 *pts, const float4 *nrm, const uint8_t *labels, uint32_t label,
                             const uint32_t *n_ptr, uint32_t n_cap, double *partial, double *mom16, hipStream_t s);
 void launch_ext_finalize(const float *hyp_plane, const uint32_t *best_plane, const float *hyp_cyl,

@@ -551,20 +551,31 @@ __global__ __launch_bounds__(256) void k_score_sel(const float4 *__restrict__ pt
 }
 
 
+// two HYPOTHESES per vector instruction (v_pk_add / v_pk_mul / v_pk_fma_f32; a hypothesis pair's parameters sit in one
+// scalar register pair, the point's coordinate is duplicated into a vector pair): every component rounds exactly like
+// the scalar operation of plane_inlier / cyl_inlier, so the decisions are theirs bit for bit
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_sub_rn(v2f a, v2f b) { v2f r; r.x = __fsub_rn(a.x, b.x); r.y = __fsub_rn(a.y, b.y); return r; }
+__device__ __forceinline__ v2f pk_mul_rn(v2f a, v2f b) { v2f r; r.x = __fmul_rn(a.x, b.x); r.y = __fmul_rn(a.y, b.y); return r; }
+__device__ __forceinline__ v2f pk_fma_rn(v2f a, v2f b, v2f c) { v2f r; r.x = __fmaf_rn(a.x, b.x, c.x); r.y = __fmaf_rn(a.y, b.y, c.y); return r; }
+
 // ---- the LAST stage: K <= 8 hypotheses on EVERY point, as a stream -------------------------------------------------------
 // lane <-> point (one coalesced 16-byte load per lane, kStPer points per lane in flight), the K hypotheses wave-uniform
 // in scalar registers, per hypothesis one compare chain, one ballot and one popcount into a scalar counter; a block adds
-// its K counters with one integer atomic each.  The stage also leaves, per point, the K-bit mask of the hypotheses it is
-// an inlier of (1 byte): the label pass reads masks and touches the rows of inliers only.  HBM-bound: 16 B read + 1 B
-// written per point.  (lane <-> hypothesis over LDS-staged points -- k_score_sel, the shape of the stages with 1024 / 128
-// hypotheses -- scored these 8 at 17-22 % of the memory roofline on the 10 M-point frame: bound by neither.)
+// its K counters with one integer atomic each.  HBM-bound for the plane (16 B per point), vector-bound for the cylinder
+// (~17 instructions per hypothesis and point).  The stage can also leave, per point, the K-bit mask of the hypotheses it
+// is an inlier of (1 byte), for a label pass that reads masks and touches the rows of inliers only: built and measured on
+// one box (tools/ab_times.sh) -- with masks the cylinder label of the 10 M-point frame takes 62 us instead of 71.5 (nearly
+// every point of a tunnel is an inlier: the rows are read anyway, the distance arithmetic is what is saved), the plane's
+// 40.6 instead of 38.0 (every row load now waits for its mask), the 1 M-point frame's 21.4 instead of 20.6 -- a wash
+// against a 2.8 ms frame, so the hand-off is off (GM_LABEL_MASKS=1 switches it on for A/B).
 constexpr int kStThreads = 256, kStPer = 4, kStK = 8;
 // A block ends with one integer atomic per hypothesis; on ONE word per hypothesis they are served one after the other
 // (~12 ns each): 814 blocks made the 1 M-point launch 16.7 us, and a grid capped at 256 blocks left too few loads in
 // flight on the 10 M-point frame (155 us for 133 MB).  The counters are kept in kStReplicas copies, 128 bytes apart --
 // block b adds to copy b % kStReplicas -- and the label pass, the only reader, sums the copies.
-constexpr int kStReplicas = 32, kStReplicaStride = 32;   // words
-template <int MODEL>
+constexpr int kStReplicas = 32, kStReplicaStride = 32;   // words (kStReplicas * kStK <= 256: the label pass reads them with one load per thread)
+template <int MODEL, bool MASKS>
 __global__ __launch_bounds__(kStThreads) void k_score_stream(const float4 *__restrict__ pts, const uint8_t *__restrict__ labels,
                                                              uint32_t want, const uint32_t *__restrict__ n_ptr, uint32_t n_host,
                                                              const float *__restrict__ hyp8, const float2 *__restrict__ band,
@@ -573,19 +584,24 @@ __global__ __launch_bounds__(kStThreads) void k_score_stream(const float4 *__res
 {
     __shared__ uint32_t red[kStThreads / kWave][kStK];
     const uint32_t n = n_ptr ? *n_ptr : n_host;
-    // the hypotheses (uniform addresses: scalar loads); slots past K score nothing
-    float h[kStK][8];
+    // the hypotheses, in pairs (uniform addresses: scalar loads; a pair's values share a scalar register pair); slots past K
+    // score nothing
+    static_assert(kStK % 2 == 0, "hypotheses are scored in pairs");
+    v2f hp[kStK / 2][8];
 #pragma unroll
     for (int k = 0; k < kStK; ++k) {
+        float hv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) h[k][q] = 0.f;
-        h[k][0] = __builtin_nanf("");
+        for (int q = 0; q < 8; ++q) hv[q] = 0.f;
+        hv[0] = __builtin_nanf("");
         if ((uint32_t)k < K) {
             const uint32_t hi = sel[k];
             const float *hy = hyp8 + 8 * (size_t)hi;
-            h[k][0] = hy[0]; h[k][1] = hy[1]; h[k][2] = hy[2]; h[k][3] = hy[3];
-            if (MODEL == 1) { const float2 bd = band[hi]; h[k][4] = hy[4]; h[k][5] = hy[5]; h[k][6] = bd.x; h[k][7] = bd.y; }
+            hv[0] = hy[0]; hv[1] = hy[1]; hv[2] = hy[2]; hv[3] = hy[3];
+            if (MODEL == 1) { const float2 bd = band[hi]; hv[4] = hy[4]; hv[5] = hy[5]; hv[6] = bd.x; hv[7] = bd.y; }
         }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { if (k & 1) hp[k >> 1][q].y = hv[q]; else hp[k >> 1][q].x = hv[q]; }
     }
     uint32_t cnt[kStK];
 #pragma unroll
@@ -602,19 +618,36 @@ __global__ __launch_bounds__(kStThreads) void k_score_stream(const float4 *__res
             if (ok[u] && labels) ok[u] = labels[i] == want;
             p[u] = pts[i < n ? i : n - 1u];
         }
+        uint32_t m[kStPer];
 #pragma unroll
         for (int u = 0; u < kStPer; ++u) {
-            const uint32_t i = base + (uint32_t)u * kStThreads + threadIdx.x;
-            uint32_t m = 0;
+            m[u] = 0u;
+            const v2f X = {p[u].x, p[u].x}, Y = {p[u].y, p[u].y}, Z = {p[u].z, p[u].z};
 #pragma unroll
-            for (int k = 0; k < kStK; ++k) {
-                const bool in = ok[u] && (MODEL == 0 ? plane_inlier(p[u].x, p[u].y, p[u].z, h[k][0], h[k][1], h[k][2], h[k][3], tau)
-                                                     : cyl_inlier(p[u].x, p[u].y, p[u].z, h[k][0], h[k][1], h[k][2], h[k][3], h[k][4],
-                                                                  h[k][5], h[k][6], h[k][7]));
-                cnt[k] += (uint32_t)__popcll(__ballot(in));   // wave-uniform
-                m |= in ? (1u << k) : 0u;
+            for (int kp = 0; kp < kStK / 2; ++kp) {
+                bool in0, in1;
+                if (MODEL == 0) {   // plane_inlier: |fma(a, x, fma(b, y, fma(c, z, d)))| < tau
+                    const v2f dist = pk_fma_rn(hp[kp][0], X, pk_fma_rn(hp[kp][1], Y, pk_fma_rn(hp[kp][2], Z, hp[kp][3])));
+                    in0 = fabsf(dist.x) < tau; in1 = fabsf(dist.y) < tau;
+                } else {            // cyl_inlier: lo2 < |v|^2 - (v.d)^2 < hi2, v = p - point on axis
+                    const v2f vx = pk_sub_rn(X, hp[kp][0]), vy = pk_sub_rn(Y, hp[kp][1]), vz = pk_sub_rn(Z, hp[kp][2]);
+                    const v2f t = pk_fma_rn(vx, hp[kp][3], pk_fma_rn(vy, hp[kp][4], pk_mul_rn(vz, hp[kp][5])));
+                    const v2f vv = pk_fma_rn(vx, vx, pk_fma_rn(vy, vy, pk_mul_rn(vz, vz)));
+                    const v2f q = pk_fma_rn(-t, t, vv);
+                    in0 = (q.x > hp[kp][6].x) & (q.x < hp[kp][7].x); in1 = (q.y > hp[kp][6].y) & (q.y < hp[kp][7].y);
+                }
+                in0 = in0 & ok[u]; in1 = in1 & ok[u];
+                cnt[2 * kp] += (uint32_t)__popcll(__ballot(in0));       // wave-uniform
+                cnt[2 * kp + 1] += (uint32_t)__popcll(__ballot(in1));
+                if (MASKS) m[u] |= (in0 ? (1u << (2 * kp)) : 0u) | (in1 ? (2u << (2 * kp)) : 0u);
             }
-            if (i < n) masks[i] = (uint8_t)m;
+        }
+        if (MASKS) {
+#pragma unroll
+            for (int u = 0; u < kStPer; ++u) {
+                const uint32_t i = base + (uint32_t)u * kStThreads + threadIdx.x;
+                if (i < n) masks[i] = (uint8_t)m[u];
+            }
         }
     }
     const int w = threadIdx.x / kWave;
@@ -655,10 +688,21 @@ __global__ __launch_bounds__(256) void k_label(const float4 *__restrict__ pts, u
     uint32_t h, wbit = 0;
     if (counts_k) {
         __shared__ uint32_t win[3];
+        __shared__ uint32_t csum[kStK];
+        if (replicas > 1u) {   // (uniform) the streaming last stage's counters: kStReplicas copies, one load per thread, summed in LDS
+            if (threadIdx.x < (uint32_t)kStK) csum[threadIdx.x] = 0u;
+            __syncthreads();
+            const uint32_t r = threadIdx.x / (uint32_t)kStK, k = threadIdx.x % (uint32_t)kStK;
+            if (r < replicas && k < K) {
+                const uint32_t v = (uint32_t)counts_k[r * (uint32_t)kStReplicaStride + k];
+                if (v) atomicAdd(&csum[k], v);
+            }
+            __syncthreads();
+        }
         if (threadIdx.x < kWave) {
             uint32_t c = 0, hi = 0xFFFFFFFFu, sl = threadIdx.x;
             if (threadIdx.x < K) {
-                for (uint32_t r = 0; r < replicas; ++r) c += (uint32_t)counts_k[r * (uint32_t)kStReplicaStride + threadIdx.x];
+                c = replicas > 1u ? csum[threadIdx.x] : (uint32_t)counts_k[threadIdx.x];
                 hi = sel[threadIdx.x];
             }
 #pragma unroll
@@ -965,9 +1009,10 @@ bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels
                              const uint32_t *n_ptr, uint32_t n_cap, const float *hyp8, float2 *band, uint32_t H,
                              double tau, uint32_t *scratch, int32_t *counts, uint32_t *best, bool prepared,
                              const uint32_t **sel_out, const int32_t **cnt_out, uint32_t *k_out, hipStream_t s, uint8_t *masks,
-                             bool *masks_written)
+                             bool *masks_written, bool *replicated_counts)
 {
     if (masks_written) *masks_written = false;
+    if (replicated_counts) *replicated_counts = false;
     if (H <= (uint32_t)kPre2Keep) {  // nothing to pre-select
         launch_score(model, pts, labels, want, n_ptr, n_cap, hyp8, band, H, tau, nullptr, counts, best, s);
         return false;
@@ -983,6 +1028,8 @@ bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels
     uint32_t *done = scratch + kPreDone;
     static const char *fs = getenv("GM_RANSAC_FINAL");   // "sel": the last stage in the lane <-> hypothesis shape (A/B timing)
     const bool stream = masks && K2 <= (uint32_t)kStK && !(fs && fs[0] == 's');
+    static const char *lm = getenv("GM_LABEL_MASKS");   // "1": the streaming stage leaves inlier masks for the label pass (A/B)
+    const bool write_masks = stream && lm && lm[0] == '1';
     if (stream) cntB = (int32_t *)(scratch + kPreCntStream);
     const uint32_t zeroB = stream ? (uint32_t)(kStReplicas * kStReplicaStride) : 0u;
     const SelectNext none{};
@@ -1011,14 +1058,15 @@ bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels
         uint32_t nb = (n_cap + kStThreads * kStPer - 1) / (kStThreads * kStPer);
         if (nb > 2048u) nb = 2048u;   // (8 waves per CU: 32 MB of loads in flight)
         if (nb == 0) nb = 1;
-        if (model == 0)
-            hipLaunchKernelGGL(k_score_stream<0>, dim3(nb), dim3(kStThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8, cb,
-                               (const uint32_t *)selB, K2, (float)tau, cntB, masks);
-        else
-            hipLaunchKernelGGL(k_score_stream<1>, dim3(nb), dim3(kStThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8, cb,
-                               (const uint32_t *)selB, K2, (float)tau, cntB, masks);
+#define GM_STREAM(M, MK)                                                                                                   \
+    hipLaunchKernelGGL((k_score_stream<M, MK>), dim3(nb), dim3(kStThreads), 0, s, pts, labels, want, n_ptr, n_cap, hyp8, cb, \
+                       (const uint32_t *)selB, K2, (float)tau, cntB, MK ? masks : (uint8_t *)nullptr)
+        if (model == 0) { if (write_masks) GM_STREAM(0, true); else GM_STREAM(0, false); }
+        else { if (write_masks) GM_STREAM(1, true); else GM_STREAM(1, false); }
+#undef GM_STREAM
         *sel_out = selB; *cnt_out = cntB; *k_out = K2;
-        if (masks_written) *masks_written = true;
+        if (masks_written) *masks_written = write_masks;
+        if (replicated_counts) *replicated_counts = true;
         return true;
     }
     if (model == 0) score_stage_sel<0>(pts, labels, want, n_ptr, n_cap, hyp8, cb, selB, K2, tau, 1u, cntB, none, s);
@@ -1030,7 +1078,7 @@ bool launch_score_preemptive(int model, const float4 *pts, const uint8_t *labels
 uint32_t launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t want, uint32_t label, const uint32_t *n_ptr,
                       uint32_t n_cap, const float *hyp8, const float2 *band, uint32_t *best, double tau, int init,
                       const uint32_t *sel, const int32_t *counts_k, uint32_t K, hipStream_t s, const float4 *nrm,
-                      double *mom_partial, const uint8_t *masks)
+                      double *mom_partial, const uint8_t *masks, bool replicated_counts)
 {
     // counts_k != nullptr: winner = best of the K (<= 64) finally re-scored hypotheses in (sel[K], counts_k[K])
     uint32_t nb = (n_cap + 255) / 256;
@@ -1046,7 +1094,7 @@ uint32_t launch_label(int model, const float4 *pts, uint8_t *labels, uint32_t wa
     if (nb == 0) nb = 1;
 #define GM_LABEL(M, MO)                                                                                                 \
     hipLaunchKernelGGL((k_label<M, MO>), dim3(nb), dim3(256), 0, s, pts, labels, want, label, n_ptr, n_cap, hyp8, band, \
-                       best, (float)tau, init, counts_k, sel, K, nrm, mom_partial, masks, masks ? (uint32_t)kStReplicas : 1u)
+                       best, (float)tau, init, counts_k, sel, K, nrm, mom_partial, masks, replicated_counts ? (uint32_t)kStReplicas : 1u)
     if (model == 0) { if (mom_partial) GM_LABEL(0, 1); else GM_LABEL(0, 0); }
     else { if (mom_partial) GM_LABEL(1, 1); else GM_LABEL(1, 0); }
 #undef GM_LABEL

@@ -56,6 +56,14 @@ rows = {
     #  normals of its inliers -- counted for every point, an upper bound)
     "gm::k_label<0, 1>": ("plane inlier labelling + plane-segment moments", 12 * n_v + n_v, 16 * n_v + n_v),
     "gm::k_label<1, 1>": ("cylinder inlier labelling + cylinder-segment moments (normals of the inliers)", 12 * n_v + n_v + 12 * n_v, 16 * n_v + 2 * n_v + 16 * n_v),
+    # RANSAC scoring (SURVEY par. 8d: 12 N'' per pass, all hypotheses of the stage in one pass).  The last stage (8
+    # hypotheses on every point) streams; the earlier stages see every 64th / 16th point: 12 B of each point they score
+    "gm::k_score_stream<0>": ("plane RANSAC, last stage: 8 hypotheses on every point (streaming scorer)", 12 * n_v, 16 * n_v),
+    "gm::k_score_stream<1>": ("cylinder RANSAC, last stage: 8 hypotheses on every point (streaming scorer)", 12 * n_v, 16 * n_v),
+    "gm::k_score<0>": ("plane RANSAC, stage 1: 1024 hypotheses on every 64th point", 12 * (n_v // 64), 16 * (n_v // 64)),
+    "gm::k_score<1>": ("cylinder RANSAC, stage 1: 1024 hypotheses on every 64th point", 12 * (n_v // 64), 16 * (n_v // 64)),
+    "gm::k_score_sel<0, 256>": ("plane RANSAC, stage 2: 128 hypotheses on every 16th point", 12 * (n_v // 16), 16 * (n_v // 16)),
+    "gm::k_score_sel<1, 256>": ("cylinder RANSAC, stage 2: 128 hypotheses on every 16th point", 12 * (n_v // 16), 16 * (n_v // 16)),
     "gm::k_segment_moments": ("per-segment covariance (points + normals of one label)", 24 * n_v + n_v, 32 * n_v + n_v),
     "gm::k_frame_moments": ("per-segment covariance, both segments in one pass (labels + points; normals of cylinder inliers)", 12 * n_v + n_v, 32 * n_v + n_v),
 }
