@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const uint32_t *_
                                                                double inv_nx, double inv_group,
                                                                uint2 *__restrict__ row_bounds /* [ny*nz]: begin, end */, uint32_t nrows,
                                                                uint2 *__restrict__ tiles, uint32_t tiles_cap, uint32_t tile_seg,
-                                                               ScanState st)
+                                                               ScanState st, uint32_t single_class)
 {
     constexpr uint64_t kAggregate = 1ull << 32, kInclusive = 2ull << 32;
     __shared__ uint32_t wstart[kTbThreads / kWave];
@@ -308,6 +308,9 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const uint32_t *_
                     // the tiles by cost: class 0 = longest
                     const uint32_t c8 = div_inv(ext * (uint32_t)kTileClasses, group, inv_group);
                     tcls[j] = (uint32_t)(kTileClasses - 1) - (c8 < (uint32_t)kTileClasses - 1u ? c8 : (uint32_t)kTileClasses - 1u);
+                    // single_class: every tile in the last list (the one that can hold them all), i.e. plain position order --
+                    // what a context that keeps several frames in flight wants (launch_grid_and_normals)
+                    if (single_class) tcls[j] = (uint32_t)(kTileClasses - 1);
                 }
             }
         }
@@ -1819,10 +1822,18 @@ void launch_grid_and_normals(const GridParams &g, const VoxDense &vd, Slot &sl, 
         ScanState st = next_scan(sl);
         st.status = sl.tile_rec;
         st.ticket = sl.sort.ticket + 1;
+        // Tile order.  Cost classes (longest tiles first) shorten the kernel's drain: 147.5 us against 157 in position order,
+        // alone on the chip.  They also spread what runs at any one time over the whole frame: 146.6 MB of HBM traffic per
+        // launch against 125, and with four frames in flight that costs more than the drain -- which the other frames'
+        // kernels fill anyway -- saves: 0.231 ms per step against 0.219 in position order (tools/sweep_classes.sh, one
+        // box).  So a context that keeps several frames in flight (n_slots > 1) cuts in position order, a context that runs
+        // one frame at a time by cost class.  GM_TILE_ORDER=classes|position overrides.
+        static const char *to = getenv("GM_TILE_ORDER");
+        const uint32_t single_class = to ? (to[0] == 'p' ? 1u : 0u) : (sl.pipelined ? 1u : 0u);
         hipLaunchKernelGGL(k_rows_and_tiles, dim3(tile_cutter_blocks(n_cap)), dim3(kTbThreads), 0, s, (const uint32_t *)skeys, sl.ctr,
                            (uint32_t)g.nx, (uint32_t)(kTileSpan * (g.xreach - 1)), inv_below((uint32_t)g.nx),
                            inv_below((uint32_t)(kTileSpan * (g.xreach - 1)) + 1u), sl.row_bounds, (uint32_t)g.ny * (uint32_t)g.nz, sl.tiles,
-                           sl.tiles_cap, sl.tile_seg, st);
+                           sl.tiles_cap, sl.tile_seg, st, single_class);
     }
     // one wave per tile: four tiles per block
     // A wave per tile for twice the tiles of a dense frame (n / 64: full 64-point tiles); a frame with more -- sparse rows
