@@ -58,8 +58,8 @@ rows = {
     "gm::k_label<1, 1>": ("cylinder inlier labelling + cylinder-segment moments (normals of the inliers)", 12 * n_v + n_v + 12 * n_v, 16 * n_v + 2 * n_v + 16 * n_v),
     # RANSAC scoring (SURVEY par. 8d: 12 N'' per pass, all hypotheses of the stage in one pass).  The last stage (8
     # hypotheses on every point) streams; the earlier stages see every 64th / 16th point: 12 B of each point they score
-    "gm::k_score_stream<0>": ("plane RANSAC, last stage: 8 hypotheses on every point (streaming scorer)", 12 * n_v, 16 * n_v),
-    "gm::k_score_stream<1>": ("cylinder RANSAC, last stage: 8 hypotheses on every point (streaming scorer)", 12 * n_v, 16 * n_v),
+    "gm::k_score_stream<0, false>": ("plane RANSAC, last stage: 8 hypotheses on every point (streaming scorer)", 12 * n_v, 16 * n_v),
+    "gm::k_score_stream<1, false>": ("cylinder RANSAC, last stage: 8 hypotheses on every point (streaming scorer)", 12 * n_v, 16 * n_v),
     "gm::k_score<0>": ("plane RANSAC, stage 1: 1024 hypotheses on every 64th point", 12 * (n_v // 64), 16 * (n_v // 64)),
     "gm::k_score<1>": ("cylinder RANSAC, stage 1: 1024 hypotheses on every 64th point", 12 * (n_v // 64), 16 * (n_v // 64)),
     "gm::k_score_sel<0, 256>": ("plane RANSAC, stage 2: 128 hypotheses on every 16th point", 12 * (n_v // 16), 16 * (n_v // 16)),
