@@ -330,8 +330,9 @@ static gm_status enqueue_launches(gm_ctx *ctx, Slot &sl, const RowLayout &rows, 
     const uint32_t *n_dev = nullptr;
     if (sl.capturing) {
         sl.scan_seq = 0;
-        // the frame's point count travels through a pinned word (the node's addresses are fixed, the value is not)
-        GM_HIP(ctx, hipMemcpyAsync(sl.frame_in, sl.h_frame_in, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        // the frame's point count -- and the address of device-resident rows -- travel through pinned words (the node's
+        // addresses are fixed, the values are not)
+        GM_HIP(ctx, hipMemcpyAsync(sl.frame_in, sl.h_frame_in, 4 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         n_dev = sl.frame_in;
     }
     {
@@ -346,7 +347,7 @@ static gm_status enqueue_launches(gm_ctx *ctx, Slot &sl, const RowLayout &rows, 
             z.ptr[3] = sl.sort.totals; z.words8[3] = radix_totals_bytes() / 8;
             z.ptr[4] = sl.sort.rec; z.words8[4] = (radix_record_words(ns, cell_key_bits(g)) + 1) / 2;   // records of the cell sort's chained scans
         }
-        z.frame_counter = sl.frame_in + 1;
+        z.frame_counter = sl.frame_in + 4;
         launch_zero_fill(z, s);
     }
     launch_crop(rows, n, lo, hi, g, sl, s, ns, n_dev, true);   // (also counts the digit totals of the cell sort)
@@ -492,6 +493,10 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
         st = enqueue_launches(ctx, sl, rows, n, ns, g, vd, lo, hi);
         if (st != GM_OK) return st;
     } else {
+        // device-resident rows are read through a device word: their address is not part of what a capture freezes
+        // (the row mode, which depends on the address's alignment, is)
+        const uint8_t *rows_at = rows.data;
+        if (on_dev) { rows.data = nullptr; rows.data_at = reinterpret_cast<const uint8_t *const *>(sl.frame_in + 2); }
         unsigned char key[sizeof(sl.graph_key[0])];
         uint32_t klen = 0;
         auto put = [&](const void *p, size_t len) { memcpy(key + klen, p, len); klen += (uint32_t)len; };
@@ -521,9 +526,11 @@ gm_status enqueue_frame(gm_ctx *ctx, Slot &sl, const gm_cloud *cloud, bool block
             GM_HIP(ctx, ie);
             memcpy(sl.graph_key[gi], key, sizeof(key));
             sl.graph_key_len[gi] = klen;
+            ++sl.graph_captures;
         }
         sl.graph_used[gi] = ++sl.graph_clock;
         sl.h_frame_in[0] = n;
+        memcpy(sl.h_frame_in + 2, &rows_at, sizeof(rows_at));
         GM_HIP(ctx, hipGraphLaunch(sl.graph_exec[gi], s));
     }
     record(ctx, sl, 8);
@@ -714,6 +721,13 @@ gm_status gm_enqueue_ransac(gm_ctx *ctx, Slot &sl, uint32_t n_cap, uint32_t scat
 
 extern "C" {
 
+// diagnostic (tests): launch chains captured on a slot so far -- a replayed frame does not add to it
+int gm_debug_graph_captures(gm_ctx *ctx, uint32_t slot)
+{
+    if (!ctx || slot >= ctx->n_slots) return -1;
+    return (int)ctx->slots[slot].graph_captures;
+}
+
 gm_status gm_host_alloc(gm_ctx *ctx, size_t bytes, void **out)
 {
     if (!ctx || !out) return fail(ctx, GM_ERR_INVALID_ARG, "gm_host_alloc: NULL argument");
@@ -842,11 +856,11 @@ gm_status gm_create(const gm_config *cfg, gm_ctx **out)
             GM_HIP(ctx, dmalloc(sl.voxp, 1));
             GM_HIP(ctx, dmalloc(sl.d_out, 1));
             GM_HIP(ctx, dmalloc(sl.partials, (size_t)kScatterBlocks * 6));
-            GM_HIP(ctx, dmalloc(sl.frame_in, 4));
-            GM_HIP(ctx, hipMemset(sl.frame_in, 0, 16));
+            GM_HIP(ctx, dmalloc(sl.frame_in, 8));
+            GM_HIP(ctx, hipMemset(sl.frame_in, 0, 32));
             if (const char *e = getenv("GM_TEST_FRAME_COUNTER")) {   // tests only: start near the replayed epochs' wrap
                 const uint32_t v = (uint32_t)strtoul(e, nullptr, 0);
-                GM_HIP(ctx, hipMemcpy(sl.frame_in + 1, &v, 4, hipMemcpyHostToDevice));
+                GM_HIP(ctx, hipMemcpy(sl.frame_in + 4, &v, 4, hipMemcpyHostToDevice));
                 sl.frames_enqueued = v;
             }
             GM_HIP(ctx, hipHostMalloc((void **)&sl.h_frame_in, 16, hipHostMallocDefault));

@@ -16,6 +16,9 @@ namespace gm {
 // (pcl::fromROSMsg, /root/reference src/geometric_mapping.cpp:55).
 struct RowLayout {
     const uint8_t *data;
+    // When set, the rows start at *data_at instead (a device word): a captured launch chain reads device-resident rows through
+    // it, so that a frame handed over at another address replays the same graph (the pointer travels like the point count).
+    const uint8_t *const *data_at;
     uint32_t step, ox, oy, oz;
     uint32_t mode;  // 0: 16-byte rows x,y,z at 0/4/8 (one dwordx4 load)  1: 4-byte aligned  2: byte loads
     uint32_t bswap; // PointCloud2.is_bigendian
@@ -60,14 +63,15 @@ struct Slot {
     // graph replay (GM_CFG_GRAPH): the frame's launch chain is captured once per (sizes, layout, configuration) and replayed
     bool capturing = false;             // the launches being enqueued go into a stream capture
     bool kernel_timed = false;          // ev_k0 / ev_k1 bracket the last frame's k_normals (not in a replayed frame)
-    uint32_t *frame_in = nullptr;       // device: [0] = points of the frame, [1] = frames replayed so far (epochs)
-    uint32_t *h_frame_in = nullptr;     // pinned: [0] = points of the frame (copied by a node of the graph)
+    uint32_t *frame_in = nullptr;       // device: [0] = points of the frame, [2..3] = address of device-resident rows, [4] = frames replayed so far (epochs)
+    uint32_t *h_frame_in = nullptr;     // pinned: words [0..3] of frame_in (copied by a node of the graph)
     static constexpr int kGraphs = 4;   // cached captures (a caller that rotates a few device buffers keeps them all)
     hipGraphExec_t graph_exec[kGraphs] = {};
     unsigned char graph_key[kGraphs][512] = {};  // everything the captured launches froze
     uint32_t graph_key_len[kGraphs] = {};
     uint64_t graph_used[kGraphs] = {};  // last use (least recently used is replaced)
     uint64_t graph_clock = 0;
+    uint32_t graph_captures = 0;        // launch chains captured on this slot so far (gm_debug_graph_captures: tests)
     uint32_t alloc_gen = 0;             // bumped whenever a device buffer of the slot is (re)allocated
     SortScratch sort = {};
     unsigned long long *tile_rec = nullptr;   // [cutter blocks + 1][kTileListClasses] records of the tile cutter's chained scan
@@ -117,7 +121,7 @@ inline ScanState next_scan(Slot &sl)
     st.status = sl.blk;
     if (sl.capturing) {   // (replayed launches derive their epoch on the device)
         st.epoch = sl.scan_seq++ & 31u;
-        st.frame_ptr = sl.frame_in + 1;
+        st.frame_ptr = sl.frame_in + 4;
     } else {
         // 1 .. 2^29-2, never 0.  When the counter wraps, the records are cleared (on the slot's stream, behind every
         // launch that wrote them): a record left at a tile index that no launch of the last 2^29 has reached would

@@ -22,7 +22,7 @@ struct RowReader {
     RowLayout L;
     __device__ __forceinline__ void load(uint32_t i, float &x, float &y, float &z) const
     {
-        const uint8_t *row = L.data + (size_t)i * L.step;
+        const uint8_t *row = (L.data_at ? *L.data_at : L.data) + (size_t)i * L.step;
         if (L.mode == 0) {
             const float4 v = *reinterpret_cast<const float4 *>(row);   // (a non-temporal load here: no change, 91.2 vs 90.7 us at 10 M points)
             x = v.x; y = v.y; z = v.z;

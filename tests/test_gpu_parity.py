@@ -379,6 +379,43 @@ def test_process_frame_device_resident_rows(ctx, oc):
     assert np.array_equal(res["scatter6"], ref["scatter6"])
 
 
+def test_graph_replays_device_resident_rows_at_any_address(gm):
+    """GM_CFG_GRAPH with rows resident in HBM: the address of the rows travels through a device word like the point count,
+    so frames handed over at different addresses replay ONE captured chain (it used to be re-captured per address) and
+    every one of them equals the frame enqueued launch by launch; rows at a 4-byte-aligned address read with another row
+    mode and take a second capture."""
+    torch = pytest.importorskip("torch")
+    from geometric_mapping_amd import _lib
+    lib = _lib.load()
+    frames = [synth.tunnel_frame(60000 - 37 * k, seed=70 + k, outlier_frac=0.01) for k in range(6)]
+    pool = torch.zeros(6 * 60000 * 4 + 64, dtype=torch.float32, device="cuda")
+    keys = ("n_cropped", "n_valid", "n_voxels", "eigenvalues", "eigenvectors", "scatter6")
+    fl = _lib.GM_CFG_DEFAULT | _lib.GM_CFG_RANSAC_CYLINDER
+    with gm.GeometricMapping(neighborRadius=0.4, flags=fl) as a, gm.GeometricMapping(neighborRadius=0.4, flags=fl | _lib.GM_CFG_GRAPH) as b:
+        def run(k, first_word):
+            xyz = frames[k]
+            rows = np.zeros((len(xyz), 4), np.float32)
+            rows[:, :3] = xyz
+            view = pool[first_word:first_word + rows.size]
+            view.copy_(torch.from_numpy(rows.reshape(-1)))
+            torch.cuda.synchronize()
+            rb = b.process_frame(b.cloud_from_device(view.data_ptr(), len(xyz), 16))
+            ra = a.process_frame(xyz)
+            for key in keys:
+                assert np.array_equal(np.asarray(ra[key]), np.asarray(rb[key]), equal_nan=True), key
+            assert np.array_equal(np.asarray(ra["cylinder"]), np.asarray(rb["cylinder"]), equal_nan=True)
+            assert np.array_equal(a.normals(), b.normals(), equal_nan=True)
+            assert np.array_equal(a.cropped_cloud()[0], b.cropped_cloud()[0])
+        for k in range(6):
+            run(k, k * 60000 * 4)                      # six addresses, all 16-byte aligned
+        assert lib.gm_debug_graph_captures(b._ctx, 0) == 1
+        run(0, 1)                                      # 4-byte aligned rows: another row mode, its own capture
+        run(1, 60000 * 4 + 1)
+        assert lib.gm_debug_graph_captures(b._ctx, 0) == 2
+        run(2, 0)                                      # ... and the first capture is still there
+        assert lib.gm_debug_graph_captures(b._ctx, 0) == 2
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_streaming_slots(gm, oc, graph):
     """(graph: every slot replays its own captured launch chain, GM_CFG_GRAPH)"""
