@@ -1367,6 +1367,27 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             if (vd.enabled) voxel_sums(vox_ok, q, vd, vox_table);
             return;
         }
+        // ---- The usual grid: the windows in STREAM coordinates.  The tile's candidates form one stream of image slots: the
+        // windows of its 9 rows one after the other, each starting on an octet of slots.  S_r = first slot of row r.  Every
+        // window end (lane 4r + 2g: begin, + 1: end of (row r, group g)) becomes its position in that stream; the register's
+        // spare lanes take S_{r+1} (lanes 40 + r) and rb_r - S_r (lanes 50 + r: sorted position = slot + that).  What a chunk
+        // holds is then arithmetic on its first slot -- no walk over rows and pieces (that walk, ~70 scalar and readlane
+        // instructions per piece in a dependent chain, was a fifth of a tile's time: GM_PH_ASSEMBLE).
+        uint32_t gs = 0, stream_total = 0, nxt_c = 0;
+        const int endl = 2 * (ngroups - 1) + 1;   // lane offset of the end of a row's last group
+        if (!FINE) {
+            const int rl = lane & ~3;
+            const uint32_t rb = __shfl(sb, rl, kWave), re = __shfl(sb, rl + endl, kWave);   // the row's window, all groups
+            const bool rowlane = lane < 36;
+            const uint32_t len = rowlane ? re - rb : 0u;
+            const uint32_t padded = (len + 7u) & ~7u;
+            const uint32_t incl = wave_inclusive_scan((rowlane && (lane & 3) == 0) ? padded : 0u);   // S_{r+1} on the row's four lanes
+            const uint32_t srow = incl - padded;                                                     // S_r
+            const uint32_t s_next = __shfl(incl, 4 * (lane - 40), kWave);        // (lanes 40 .. 48)
+            const uint32_t off_r = __shfl(rb - srow, 4 * (lane - 50), kWave);    // (lanes 50 .. 58)
+            gs = rowlane ? srow + (sb - rb) : ((lane >= 40 && lane < 49) ? s_next : ((lane >= 50 && lane < 59) ? off_r : 0u));
+            stream_total = __builtin_amdgcn_readlane(gs, 48);
+        }
         GM_PH_STAMP(ph_t2);
         GM_PH_ADD(1, ph_t2 - ph_t1);   // origin, query-side operand fragments
         // ---- the candidate stream.  The tile's candidates -- the windows of its (2D+1)^2 rows, one after the other -- are
@@ -1385,7 +1406,43 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         uint32_t n_lo[kMxGroups], n_hi[kMxGroups], n_slots = 0;   // the chunk being fetched: block range per group, slots used
         float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;    // its rows (this lane's slot pair)
         uint32_t pidx = qs, pv = 0;               // sorted position of the pair's first candidate; bit 0 / 1: first / second slot holds one
-        auto assemble = [&]() {
+        auto assemble_stream = [&]() {   // the usual grid
+            n_slots = 0; pv = 0; pidx = qs;
+#pragma unroll
+            for (int gi = 0; gi < kMxGroups; ++gi) { n_lo[gi] = 0xFFFFFFFFu; n_hi[gi] = 0u; }
+            if (nxt_c >= stream_total) return;   // wave-uniform
+            const uint32_t c0 = nxt_c, c1 = nxt_c + (uint32_t)kMdChunk;
+            nxt_c = c1;
+            n_slots = stream_total - c0 < (uint32_t)kMdChunk ? stream_total - c0 : (uint32_t)kMdChunk;
+            // this lane's slot pair: its row = the number of row ends at or before its first slot (empty rows end where they begin)
+            const uint32_t sl0 = c0 + 2u * (uint32_t)lane;
+            uint32_t r = 0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) r += sl0 >= (uint32_t)__builtin_amdgcn_readlane(gs, 40 + k) ? 1u : 0u;
+            r = r > 8u ? 8u : r;   // (past the stream: the last row's end says so below)
+            const uint32_t off = __shfl(gs, 50 + (int)r, kWave), lim = __shfl(gs, 4 * (int)r + endl, kWave);
+            const bool v0 = sl0 < lim, v1 = sl0 + 1u < lim;
+            pidx = v0 ? sl0 + off : qs;
+            pv = v0 ? (v1 ? 3u : 1u) : 0u;
+            // per group: the chunk's part of its windows.  Windows follow each other in the stream, so the run of blocks that
+            // covers them goes from the first one that reaches into the chunk to the last one
+            const uint32_t other = __shfl_xor(gs, 1, kWave);   // (a begin lane reads its end)
+            const uint32_t cb = gs > c0 ? gs : c0, ce = other < c1 ? other : c1;
+            const uint64_t m = __ballot((lane & 1) == 0 && lane < 36 && ce > cb);
+            const uint32_t cb8 = (cb & ~7u) - c0, ce0 = ce - c0;
+#pragma unroll
+            for (int gi = 0; gi < kMxGroups; ++gi) {
+                if (gi >= ngroups) break;
+                const uint64_t mg = m & (gi ? 0x444444444ull : 0x111111111ull);
+                if (mg) {   // wave-uniform
+                    n_lo[gi] = __builtin_amdgcn_readlane(cb8, (int)__builtin_ctzll(mg));
+                    n_hi[gi] = __builtin_amdgcn_readlane(ce0, 63 - (int)__builtin_clzll(mg));
+                }
+            }
+            pa = spts4[pidx];
+            pb = spts4[pidx + (pv >> 1)];
+        };
+        auto assemble_walk = [&]() {     // finer grids: rows in passes of 32
             n_slots = 0; pv = 0; pidx = qs;
 #pragma unroll
             for (int gi = 0; gi < kMxGroups; ++gi) { n_lo[gi] = 0xFFFFFFFFu; n_hi[gi] = 0u; }
@@ -1435,6 +1492,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                 pb = spts4[pidx + (pv >> 1)];
             }
         };
+        auto assemble = [&]() { if (FINE) assemble_walk(); else assemble_stream(); };
         assemble();
         while (n_slots) {
             uint32_t c_lo[kMxGroups], c_hi[kMxGroups];
@@ -1492,12 +1550,20 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                     feat[((uint32_t)kMdChunk / 8u + ((uint32_t)lane >> 2)) * (uint32_t)kMdOctetWords + ((uint32_t)lane & 3u) + (uint32_t)kRowQ[0] * 4u] = 0x71807180u;
             }
             wave_lds_fence();
+#ifdef GM_PH_ASSEMBLE   // (diagnostic: the next chunk's assembly on its own, in the slot of the -- empty -- wait for the rows)
+            GM_PH_STAMP(ph_ca);
+#endif
 #if GM_NORMALS_PREFETCH
             assemble();   // the next chunk: its rows are in flight during the pair loops below
 #endif
             GM_PH_STAMP(ph_c2);
 #ifdef GM_NORMALS_PHASES
+#ifdef GM_PH_ASSEMBLE
+            GM_PH_ADD(2, ph_c2 - ph_ca);
+            GM_PH_ADD(3, ph_ca - ph_c1);
+#else
             GM_PH_ADD(3, ph_c2 - ph_c1);   // feature image of the chunk
+#endif
 #endif
 #pragma unroll
             for (int gi = 0; gi < kMxGroups; ++gi) {

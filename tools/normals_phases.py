@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Where a wave of k_normals spends a tile (diagnostic build: make EXTRA=-DGM_NORMALS_PHASES).
-Shader-clock ticks (s_memtime) summed over all tiles, per phase; the stamps themselves cost ~10 %."""
+"""Where a wave of k_normals spends a tile (diagnostic build: tools/build_variants.sh ph "-DGM_NORMALS_PHASES").
+Shader-clock ticks (s_memtime) summed over all tiles, per phase; the stamps themselves cost ~10 %.
+Built with -DGM_PH_ASSEMBLE as well, the slot "chunk_load_wait" (empty otherwise: the rows are prefetched) holds the
+assembly of the next chunk and "chunk_features" the feature image alone."""
 import argparse, ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import geometric_mapping_amd as g
