@@ -1240,7 +1240,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             const int a = (r % side) - gD, b = (r / side) - gD;
             const int yy = cy + a, zz = cz + b;
             const int reach = (k >> 1) < nrows ? (FINE ? (int)g.reach[a < 0 ? -a : a][b < 0 ? -b : b] : g.xreach) : 0;
-            uint32_t key_b = 0, key_e = 0, lo1 = 0, hi1 = 0;
+            uint32_t key_b = 0, key_e = 0, lo1 = 0, hi1 = 0, row_key0 = 0;   // row_key0: the row's first key
             if (reach > 0 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
                 const uint32_t nrow = (uint32_t)(zz * g.ny + yy);
                 const uint2 rb = row_bounds[nrow];
@@ -1248,7 +1248,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                 const int xa = lo_fx > reach ? lo_fx - reach : 0;
                 const int xb = hi_fx + reach < g.nx - 1 ? hi_fx + reach : g.nx - 1;
                 key_b = rbk + (uint32_t)xa; key_e = rbk + (uint32_t)xb + 1u;
-                lo1 = rb.x; hi1 = rb.y;
+                lo1 = rb.x; hi1 = rb.y; row_key0 = rbk;
             }
             if (FINE) {
                 uint32_t lo2 = lo1, hi2 = hi1;
@@ -1266,6 +1266,22 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                 // the chain: with the interpolated guess alone -- two loads, wrong windows -- the kernel runs 4.6 % faster,
                 // which is all a perfect search could give.)
                 const uint32_t key = (lane & 1) ? key_e : key_b;   // first position of the row whose key is >= key
+#ifndef GM_NORMALS_NO_GUIDED_PROBE
+                // A guided first round: two probes kGuide positions either side of where the key would sit in a row that
+                // covers the grid's x-range evenly.  In such a row (the tunnel's) they bracket the answer and seven
+                // halvings are left of twelve; in any other row they are two ordinary probes of the search -- the range
+                // still shrinks to one of three parts, one round is lost at worst.
+                constexpr uint32_t kGuide = 64;
+                if (hi1 - lo1 > 8u * kGuide) {
+                    const uint32_t xq = key - row_key0;   // the key's x cell (0 .. nx)
+                    const uint32_t gpos = lo1 + (uint32_t)((float)xq * (float)(hi1 - lo1) / (float)g.nx);
+                    const uint32_t pa0 = gpos > lo1 + kGuide ? gpos - kGuide : lo1;
+                    const uint32_t pb0 = gpos + kGuide < hi1 ? gpos + kGuide : hi1 - 1u;
+                    const uint32_t ka0 = skeys[pa0], kb0 = skeys[pb0];   // (lo1 <= pa0 <= pb0 < hi1 <= n)
+                    if (ka0 < key) lo1 = pa0 + 1u; else hi1 = pa0;
+                    if (pb0 >= lo1 && pb0 < hi1) { if (kb0 < key) lo1 = pb0 + 1u; else hi1 = pb0; }
+                }
+#endif
                 while (lo1 < hi1) {
                     const uint32_t m1 = (lo1 + hi1) >> 1;
                     if (skeys[m1] < key) lo1 = m1 + 1u; else hi1 = m1;   // (m1 < hi1 <= n)
