@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kTbThreads) void k_rows_and_tiles(const uint32_t *_
 #pragma unroll
     for (int j = 0; j < kTbPer; ++j) {
         if (cnt[j]) {
-            const uint2 t = make_uint2(s0 + j, tend[j] - (s0 + j));  // first query, number of queries
+            const uint2 t = make_uint2(s0 + j, (tend[j] - (s0 + j)) | (row[j] << 8));  // first query; number of queries (<= 64) | x-row << 8
             const uint32_t c = tcls[j], idx = wcls[w][c] + rank[j];
             if (idx < (c + 1u < (uint32_t)kTileClasses ? tile_seg : tiles_cap)) tiles[(size_t)c * tile_seg + idx] = t;   // (always: see Slot::tile_seg)
         }
@@ -580,7 +580,7 @@ __device__ __forceinline__ void normals_tile_valu(const NormalsArgs &A, unsigned
     const int w = 0;
     const uint32_t n = ctr->n_cropped;
     {
-        const uint32_t qs = tile.x, qn = tile.y;  // first query (sorted position), number of queries (1..64)
+        const uint32_t qs = tile.x, qn = tile.y & 0xFFu;  // first query (sorted position), number of queries (1..64); the x-row rides above
 #ifdef GM_NORMALS_TIMELINE
         const unsigned long long stat_t0 = wall_clock64();
 #endif
@@ -863,7 +863,7 @@ __device__ __forceinline__ void normals_tile_mx(const NormalsArgs &A, unsigned c
     uint32_t *feat = &mxl[w].f[0];
     const int qsel = lane & 31, half = lane >> 5;
     {
-        const uint32_t qs = tile.x, qn = tile.y;
+        const uint32_t qs = tile.x, qn = tile.y & 0xFFu;
 #ifdef GM_NORMALS_TIMELINE
         const unsigned long long stat_t0 = wall_clock64();
 #else
@@ -1188,7 +1188,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                             (uint32_t)((tr0 + 4 * tp) >> 3) * (uint32_t)(kMdOctetWords * 4) + (uint32_t)((tr0 + 4 * tp) & 7) * 2u;
     const uint32_t mom_off = (uint32_t)qsel * 16u + 8u * (uint32_t)half;   // ... and of its moment-MFMA operand reads
     {
-        const uint32_t qs = tile.x, qn = tile.y;
+        const uint32_t qs = tile.x, qn = tile.y & 0xFFu, tile_row = tile.y >> 8;   // first query, queries (1 .. 64), x-row of the tile
 #ifdef GM_NORMALS_TIMELINE
         const unsigned long long stat_t0 = wall_clock64();
 #else
@@ -1202,9 +1202,33 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
         const uint32_t qidx = qs + (active ? (uint32_t)lane : qn - 1u);
         const float4 q = spts4[qidx];
         const uint32_t kl = skeys[qidx];
-        const uint32_t ka = __builtin_amdgcn_readfirstlane(kl);
-        const uint32_t row = ka / (uint32_t)g.nx;
+        // (the tile's x-row comes with the tile: the row table below is asked before anything waits for the keys)
+        const uint32_t row = tile_row;
         const int cy = (int)(row % (uint32_t)g.ny), cz = (int)(row / (uint32_t)g.ny);
+        // ---- candidate windows.  The tile's candidates lie in the (2D+1)^2 rows around its own; they are taken in passes
+        // of up to 32 rows: lane i finds both ends of the window of (row i / 2 of the pass, group i % 2).  D = 1 (the
+        // usual grid): 9 rows, one pass.
+        const int gD = FINE ? g.D : 1;
+        const int side = 2 * gD + 1, nrows_all = side * side;
+        int nrows = 0;   // rows of the current pass
+        // which row of the grid a lane searches in a pass, and that row's entry of the row table (first / one-past-last sorted
+        // position) -- asked for here, while the query and key loads above are still in flight
+        struct LaneRow { int gg, reach; uint32_t nrow; bool ok; uint2 rb; };
+        auto lane_row = [&](int row0) -> LaneRow {
+            nrows = nrows_all - row0 < 32 ? nrows_all - row0 : 32;
+            const int k = FINE ? lane : (lane >> 1);     // (row, group) this lane works for
+            const int r = row0 + (k >> 1);
+            const int a = (r % side) - gD, b = (r / side) - gD;
+            const int yy = cy + a, zz = cz + b;
+            LaneRow R;
+            R.gg = k & 1;
+            R.reach = (k >> 1) < nrows ? (FINE ? (int)g.reach[a < 0 ? -a : a][b < 0 ? -b : b] : g.xreach) : 0;
+            R.ok = R.reach > 0 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz;
+            R.nrow = R.ok ? (uint32_t)(zz * g.ny + yy) : 0u;
+            R.rb = R.ok ? row_bounds[R.nrow] : make_uint2(0u, 0u);
+            return R;
+        };
+        const LaneRow lr0 = lane_row(0);
         const int fxl = (int)(kl - row * (uint32_t)g.nx);
         if (__ballot(active && q.x >= vd.own_lo && q.x < vd.own_hi) == 0) {  // halo-only tile (slab sharding)
             if (active) {
@@ -1214,41 +1238,28 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             }
             return;
         }
-        // ---- candidate windows.  The tile's candidates lie in the (2D+1)^2 rows around its own; they are taken in passes
-        // of up to 32 rows: lane i finds both ends of the window of (row i / 2 of the pass, group i % 2).  D = 1 (the
-        // usual grid): 9 rows, one pass.
-        const int gD = FINE ? g.D : 1;
-        const int side = 2 * gD + 1, nrows_all = side * side;
         // Window ends per (row, group).  FINE: lane i holds both ends of (row i / 2 of the pass, group i % 2) in sb / se.  The
         // usual grid: ONE end per lane -- lane 2 k holds the begin, lane 2 k + 1 the end of (row k / 2, group k % 2) in sb --
         // so the 36 searches of a tile run on 36 lanes instead of two apiece on 18: half the instructions per round.
         uint32_t sb = 0, se = 0;
-        int nrows = 0;   // rows of the current pass
         auto win_begin = [&](int r, int gg) -> uint32_t {
             return FINE ? __builtin_amdgcn_readlane(sb, r * kMxGroups + gg) : __builtin_amdgcn_readlane(sb, 2 * (r * kMxGroups + gg));
         };
         auto win_end = [&](int r, int gg) -> uint32_t {
             return FINE ? __builtin_amdgcn_readlane(se, r * kMxGroups + gg) : __builtin_amdgcn_readlane(sb, 2 * (r * kMxGroups + gg) + 1);
         };
-        auto find_windows = [&](int row0) {
-            nrows = nrows_all - row0 < 32 ? nrows_all - row0 : 32;
+        auto find_windows = [&](const LaneRow &R) {
             sb = 0; se = 0;
-            const int k = FINE ? lane : (lane >> 1);     // (row, group) this lane works for
-            const int r = row0 + (k >> 1), gg = k & 1;
+            const int gg = R.gg, reach = R.reach;
             const int lo_fx = __shfl(fxl, gg * kMxGroupLanes, kWave);
             const int hi_fx = __shfl(fxl, gg * kMxGroupLanes + kMxGroupLanes - 1, kWave);
-            const int a = (r % side) - gD, b = (r / side) - gD;
-            const int yy = cy + a, zz = cz + b;
-            const int reach = (k >> 1) < nrows ? (FINE ? (int)g.reach[a < 0 ? -a : a][b < 0 ? -b : b] : g.xreach) : 0;
             uint32_t key_b = 0, key_e = 0, lo1 = 0, hi1 = 0, row_key0 = 0;   // row_key0: the row's first key
-            if (reach > 0 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-                const uint32_t nrow = (uint32_t)(zz * g.ny + yy);
-                const uint2 rb = row_bounds[nrow];
-                const uint32_t rbk = nrow * (uint32_t)g.nx;
+            if (R.ok) {
+                const uint32_t rbk = R.nrow * (uint32_t)g.nx;
                 const int xa = lo_fx > reach ? lo_fx - reach : 0;
                 const int xb = hi_fx + reach < g.nx - 1 ? hi_fx + reach : g.nx - 1;
                 key_b = rbk + (uint32_t)xa; key_e = rbk + (uint32_t)xb + 1u;
-                lo1 = rb.x; hi1 = rb.y; row_key0 = rbk;
+                lo1 = R.rb.x; hi1 = R.rb.y; row_key0 = rbk;
             }
             if (FINE) {
                 uint32_t lo2 = lo1, hi2 = hi1;
@@ -1289,7 +1300,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                 sb = lo1;
             }
         };
-        find_windows(0);
+        find_windows(lr0);
         GM_PH_STAMP(ph_t1);
         GM_PH_ADD(0, ph_t1 - ph_t0);   // tile head: query + key loads, window search
         // Thin neighbourhoods (fewer than min_candidates candidates in the first group's windows) take the direct path
@@ -1397,7 +1408,13 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
             const bool rowlane = lane < 36;
             const uint32_t len = rowlane ? re - rb : 0u;
             const uint32_t padded = (len + 7u) & ~7u;
-            const uint32_t incl = wave_inclusive_scan((rowlane && (lane & 3) == 0) ? padded : 0u);   // S_{r+1} on the row's four lanes
+            // S_{r+1} on the row's four lanes: a scan over the rows, four lanes apiece with the same value -- lane shifts by 4
+            // and 8 inside each 16-lane DPP row, then the row totals handed on (lane 15 / 31 hold their row's total)
+            uint32_t incl = padded;
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
             const uint32_t srow = incl - padded;                                                     // S_r
             const uint32_t s_next = __shfl(incl, 4 * (lane - 40), kWave);        // (lanes 40 .. 48)
             const uint32_t off_r = __shfl(rb - srow, 4 * (lane - 50), kWave);    // (lanes 50 .. 58)
@@ -1467,7 +1484,7 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                 if (cur_r >= nrows) {   // the pass has no rows left
                     if (!FINE || row0 + 32 >= nrows_all) break;
                     row0 += 32;
-                    find_windows(row0);   // the next pass of rows (finer grids only)
+                    find_windows(lane_row(row0));   // the next pass of rows (finer grids only)
                     cur_r = 0; cur_c = row_begin(0);
                     continue;
                 }
