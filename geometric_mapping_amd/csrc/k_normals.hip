@@ -1275,7 +1275,9 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                 // change.  Round 4 again: 8 ways, then 15 probes at once = 4 round trips and 36 probe loads instead of 12 and 12:
                 // 151.5 us against 150.  What costs is the number of these loads, each lane its own cache line, not the depth of
                 // the chain: with the interpolated guess alone -- two loads, wrong windows -- the kernel runs 4.6 % faster,
-                // which is all a perfect search could give.)
+                // which is all a perfect search could give.  And once more behind the guided round below: finishing a range of
+                // <= 128 positions with 15 probes at once and then 8 -- three rounds after the row table instead of eight, the
+                // probes inside a few cache lines -- is 1.5 % slower alone and 2 % slower per pipelined step.)
                 const uint32_t key = (lane & 1) ? key_e : key_b;   // first position of the row whose key is >= key
 #ifndef GM_NORMALS_NO_GUIDED_PROBE
                 // A guided first round: two probes kGuide positions either side of where the key would sit in a row that
