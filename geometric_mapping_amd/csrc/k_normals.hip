@@ -504,6 +504,28 @@ __device__ __forceinline__ bool emit_normal(bool active, const float4 q, const d
 // ---- VoxelGrid fast path: points of a tile are spatial neighbours, so they fall into one to three voxels;
 // reduce by voxel inside the wave, then one set of integer atomics per (wave, voxel).
 // (pcl::VoxelGrid, src/tunnel_processing.cpp:217-220)
+// wave-wide sum of a 64-bit value, delivered as a wave-uniform value: data-parallel-primitive adds (row shifts inside the
+// 16-lane rows, then the row totals handed on) -- 12 moves + 6 add pairs on the vector pipe, no trip through the LDS crossbar
+// as the lane-permute formulation of wave_sum takes (12 permutes per sum, three sums per voxel of a tile)
+__device__ __forceinline__ unsigned long long wave_total_u64(unsigned long long v)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    auto step = [&](auto dpp) {
+        const uint32_t tl = dpp(lo), th = dpp(hi);
+        const uint32_t nl = lo + tl;
+        hi = hi + th + (nl < lo ? 1u : 0u);
+        lo = nl;
+    };
+    step([](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xF, 0xF, true); });
+    step([](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112 /* row_shr:2 */, 0xF, 0xF, true); });
+    step([](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114 /* row_shr:4 */, 0xF, 0xF, true); });
+    step([](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118 /* row_shr:8 */, 0xF, 0xF, true); });
+    step([](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142 /* row_bcast:15 */, 0xA, 0xF, false); });
+    step([](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143 /* row_bcast:31 */, 0xC, 0xF, false); });
+    const uint32_t rl = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63), rh = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+    return ((unsigned long long)rh << 32) | rl;
+}
+
 __device__ __forceinline__ void voxel_sums(bool vox_ok, const float4 q, const VoxDense &vd, VoxCell *__restrict__ vox_table)
 {
     const int lane = lane_id();
@@ -524,9 +546,9 @@ __device__ __forceinline__ void voxel_sums(bool vox_ok, const float4 q, const Vo
         const uint32_t k = __shfl(vkey, leader, kWave);
         const bool mine = vox_ok && vkey == k;
         const uint64_t same = __ballot(mine);
-        const unsigned long long ax = wave_sum(mine ? fx : 0ull);
-        const unsigned long long ay = wave_sum(mine ? fy : 0ull);
-        const unsigned long long az = wave_sum(mine ? fz : 0ull);
+        const unsigned long long ax = wave_total_u64(mine ? fx : 0ull);
+        const unsigned long long ay = wave_total_u64(mine ? fy : 0ull);
+        const unsigned long long az = wave_total_u64(mine ? fz : 0ull);
         if (lane == leader) {
             VoxCell *cell = vox_table + k;
             atomicAdd(&cell->sx, ax);
