@@ -121,3 +121,34 @@ def test_config3_10m_frame_over_four_ranks(gm):
         assert res["cylinder_inliers"] == c.score_frame(1, res["cylinder"][None, :], TAU)[0]
     assert abs(abs(res["plane"][2]) - 1) < 1e-2 and abs(abs(res["plane"][3]) - 1.2) < 2e-2          # floor z = -1.2
     assert abs(res["cylinder"][6] - 2.0) < 0.05 and ang(res["cylinder"][3:6], [1, 0, 0]) < 0.05
+
+
+def test_bench_line_keeps_its_contract():
+    """`python bench.py` as the driver runs it at N = 1 (a child process; fewer steps and a smaller frame so that the test
+    takes seconds): ONE JSON line on stdout whose keys, types and cross-checks are the round contract's -- BASELINE.json's
+    metric and unit, steps / warmup echoed, whole-job value = points x steps / time, `roofline` with achieved / peak / frac
+    consistent, `cpu_baseline` from the oracle, no model keys in `config`."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, steps, warmup = 200_000, 6, 2
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", str(steps), "--warmup", str(warmup), "--points", str(n),
+                          "--no-secondary", "--group-points", "0"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                   # ONE line
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert base["metric"].startswith(d["metric"]) and d["unit"] == "points/s"   # (BASELINE's string goes on ", 1/2/4/8 GPU")
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"].startswith("synthetic")
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]      # whole-job points per second
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] == 8000.0
+    assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 1e-9
+    assert rf["traffic"] is None or rf["traffic"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == d["unit"] and cb["sample"]
+    assert d["value"] > cb["value"]                                  # (a GPU that loses to the CPU oracle is a broken build)
