@@ -1299,7 +1299,11 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                 // the chain: with the interpolated guess alone -- two loads, wrong windows -- the kernel runs 4.6 % faster,
                 // which is all a perfect search could give.  And once more behind the guided round below: finishing a range of
                 // <= 128 positions with 15 probes at once and then 8 -- three rounds after the row table instead of eight, the
-                // probes inside a few cache lines -- is 1.5 % slower alone and 2 % slower per pipelined step.)
+                // probes inside a few cache lines -- is 1.5 % slower alone and 2 % slower per pipelined step.  A coarse level
+                // first (every 64th key, packed by the tile cutter into 52 KB that stay in cache: six halvings there, six
+                // between two samples) makes the head of a tile LONGER, 19.9 k -> 22.2 k clocks: a round costs its ~1 500
+                // clocks whether the line is cached or not -- it is the trip through the vector-memory pipeline under this
+                // kernel's load, not a miss, and only fewer trips help.)
                 const uint32_t key = (lane & 1) ? key_e : key_b;   // first position of the row whose key is >= key
 #ifndef GM_NORMALS_NO_GUIDED_PROBE
                 // A guided first round: two probes kGuide positions either side of where the key would sit in a row that
