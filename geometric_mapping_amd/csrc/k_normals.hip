@@ -1303,7 +1303,9 @@ __device__ __forceinline__ void normals_tile_mxd(const NormalsArgs &A, unsigned 
                 // first (every 64th key, packed by the tile cutter into 52 KB that stay in cache: six halvings there, six
                 // between two samples) makes the head of a tile LONGER, 19.9 k -> 22.2 k clocks: a round costs its ~1 500
                 // clocks whether the line is cached or not -- it is the trip through the vector-memory pipeline under this
-                // kernel's load, not a miss, and only fewer trips help.)
+                // kernel's load, not a miss, and only fewer trips help.  Fewer trips by finishing all 36 searches at once --
+                // the wave loads the <= 64 keys left of each with one coalesced instruction, ballot + population count --
+                // costs ~500 instructions: 133 -> 147 us.)
                 const uint32_t key = (lane & 1) ? key_e : key_b;   // first position of the row whose key is >= key
 #ifndef GM_NORMALS_NO_GUIDED_PROBE
                 // A guided first round: two probes kGuide positions either side of where the key would sit in a row that
